@@ -1,0 +1,60 @@
+// Library-wide pieces of the C ABI: error text, version, counter-based init, fixed-order sum.
+#include "dr_common.h"
+
+namespace dr {
+char* last_error_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+// splitmix64 -> four 16-bit uniforms -> Irwin-Hall(4) ~ N(0,1).  Integer arithmetic plus one
+// exact int->float conversion and fp32 multiplies: bit-identical on host and device.
+__host__ __device__ inline float counter_normal(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    int s = (int)(z & 0xFFFF) + (int)((z >> 16) & 0xFFFF) + (int)((z >> 32) & 0xFFFF) + (int)((z >> 48) & 0xFFFF);
+    return (float)(s - 131070) * (1.0f / 37837.227f);
+}
+
+__global__ __launch_bounds__(256) void init_normal_kernel(float* __restrict__ w, int64_t count, uint64_t seed,
+                                                          float stddev) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        w[i] = stddev * counter_normal(seed, (uint64_t)i);
+}
+
+// One block, fixed order: thread t sums x[t], x[t+1024], ... sequentially, then a fixed LDS tree.
+__global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float acc = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+}  // namespace dr
+
+extern "C" const char* dr_last_error(void) { return dr::last_error_buf(); }
+extern "C" int32_t dr_version(void) { return 100; }
+
+extern "C" int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, float stddev, void* stream) {
+    DR_REQUIRE(count >= 0, "dr_init_normal_f32: negative count");
+    if (count == 0) return DR_OK;
+    DR_REQUIRE(w != nullptr, "dr_init_normal_f32: w is NULL");
+    hipLaunchKernelGGL(dr::init_normal_kernel, dim3(dr::grid_for(count, 256, 4)), dim3(256), 0, (hipStream_t)stream,
+                       w, count, seed, stddev);
+    DR_CHECK_LAUNCH("dr_init_normal_f32");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream) {
+    DR_REQUIRE(n >= 0 && out != nullptr && (x != nullptr || n == 0), "dr_sum_f32: bad arguments");
+    hipLaunchKernelGGL(dr::sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+    DR_CHECK_LAUNCH("dr_sum_f32");
+    return DR_OK;
+}

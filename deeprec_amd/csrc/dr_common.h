@@ -1,0 +1,147 @@
+// Shared host/device helpers for the deeprec_amd HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/deeprec_amd.h"
+
+namespace dr {
+
+// ---- host-side error plumbing ---------------------------------------------
+char* last_error_buf();  // thread-local, defined in abi.hip
+
+#define DR_FAIL(code, ...)                                         \
+    do {                                                           \
+        snprintf(dr::last_error_buf(), 512, __VA_ARGS__);          \
+        return (code);                                             \
+    } while (0)
+
+#define DR_REQUIRE(cond, ...)                                      \
+    do {                                                           \
+        if (!(cond)) DR_FAIL(DR_ERR_ARG, __VA_ARGS__);             \
+    } while (0)
+
+#define DR_CHECK_LAUNCH(what)                                                          \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) DR_FAIL(DR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+    } while (0)
+
+#define DR_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) DR_FAIL(DR_ERR_LAUNCH, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Memory-bound launches: cap the grid at CUs * blocks-per-CU and grid-stride the rest
+// (256 CUs on MI355X; 8 blocks of 256 threads per CU = full 32 waves/CU).
+static inline int grid_for(int64_t work_items, int block, int items_per_block_iter = 1) {
+    int64_t per = (int64_t)block * items_per_block_iter;
+    int64_t g = (work_items + per - 1) / per;
+    if (g < 1) g = 1;
+    const int64_t cap = 256 * 8;
+    return (int)(g > cap ? cap : g);
+}
+
+// ---- vector-width selection -------------------------------------------------
+// A row of k floats is moved as k/V vectors of V floats (V = 4, 2 or 1) by LPR lanes
+// per row (power of two <= 64), so 64/LPR rows are in flight per wavefront.
+struct RowShape {
+    int V;    // floats per lane-vector
+    int LPR;  // lanes per row
+};
+static inline RowShape row_shape(int k) {
+    RowShape s;
+    s.V = (k % 4 == 0) ? 4 : ((k % 2 == 0) ? 2 : 1);
+    int cpr = k / s.V;
+    int l = 1;
+    while (l < cpr && l < 64) l <<= 1;
+    s.LPR = l;
+    return s;
+}
+
+template <int V>
+struct VecT;
+template <>
+struct VecT<4> { using type = float4; };
+template <>
+struct VecT<2> { using type = float2; };
+template <>
+struct VecT<1> { using type = float; };
+
+template <int V>
+__device__ __forceinline__ void vload(float (&r)[V], const float* p) {
+    if constexpr (V == 4) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    } else if constexpr (V == 2) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        r[0] = t.x; r[1] = t.y;
+    } else {
+        r[0] = *p;
+    }
+}
+template <int V>
+__device__ __forceinline__ void vstore(float* p, const float (&r)[V]) {
+    if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+    } else if constexpr (V == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(r[0], r[1]);
+    } else {
+        *p = r[0];
+    }
+}
+
+// sum over the LPR lanes that share a row (xor butterfly; every lane gets the result)
+template <int LPR>
+__device__ __forceinline__ float subwave_sum(float x) {
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// ---- optimizer row math ([TF-ext] ApplyAdam / ApplyAdagrad / ApplyRMSProp / SGD) ----
+// Separate roundings (the library is built with -ffp-contract=off) so the numpy oracle
+// reproduces the same sequence.
+struct OptP {
+    int kind, reg_mode;
+    float lr, alpha, omb1, omb2, eps, omrho, momentum, reg;
+};
+static inline OptP make_optp(const dr_opt_params* o) {
+    OptP p;
+    p.kind = o->kind;
+    p.reg_mode = o->reg_mode;
+    p.lr = o->lr;
+    p.alpha = o->alpha;
+    p.omb1 = 1.0f - o->beta1;
+    p.omb2 = 1.0f - o->beta2;
+    p.eps = o->eps;
+    p.omrho = 1.0f - o->rho;
+    p.momentum = o->momentum;
+    p.reg = o->reg;
+    return p;
+}
+
+template <int KIND>
+__device__ __forceinline__ void opt_apply(float& w, float& s0, float& s1, float g, const OptP& o) {
+    if constexpr (KIND == DR_OPT_SGD) {
+        w = w - o.lr * g;
+    } else if constexpr (KIND == DR_OPT_ADAM) {
+        s0 = s0 + (g - s0) * o.omb1;
+        s1 = s1 + (g * g - s1) * o.omb2;
+        w = w - (s0 * o.alpha) / (sqrtf(s1) + o.eps);
+    } else if constexpr (KIND == DR_OPT_ADAGRAD) {
+        s0 = s0 + g * g;
+        w = w - (g * o.lr) * (1.0f / sqrtf(s0));
+    } else {  // RMSPROP
+        s0 = s0 + (g * g - s0) * o.omrho;
+        s1 = s1 * o.momentum + (g * o.lr) / sqrtf(s0 + o.eps);
+        w = w - s1;
+    }
+}
+
+}  // namespace dr

@@ -1,0 +1,121 @@
+// K1: embedding lookup  out[n,:] = table[ids[n],:]   (HBM-bound)
+//
+// Work decomposition: a row of k floats is moved by LPR lanes as V-float vectors, so one
+// wavefront moves 64/LPR rows per pass (k=128: 32 lanes x float4, 2 rows per pass).  Each
+// wave keeps U passes in flight (ids first, then the U independent row loads) so that a CU
+// has >= 64 KB outstanding, which is what hides an HBM miss (MI355X_MICROARCH.md, "Indexed
+// rows").  Output rows are written with streaming (non-temporal) stores: they are never
+// re-read by this kernel and must not evict table rows that repeat (popular items) from L2.
+#include "dr_common.h"
+
+namespace dr {
+
+template <int V, int LPR, int U, typename IdT>
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ table, int64_t rows,
+                                                     int k, const IdT* __restrict__ ids, int64_t n,
+                                                     float* __restrict__ out,
+                                                     int* __restrict__ oob_count) {
+    constexpr int RPW = 64 / LPR;          // rows per wave pass
+    constexpr int RPB = RPW * 4;           // rows per block pass (4 waves)
+    const int tid = threadIdx.x;
+    const int sub = tid / LPR;             // which row of the block pass
+    const int lane = tid % LPR;
+    const int cpr = k / V;                 // vectors per row
+    int bad = 0;
+    // block-cyclic over groups of RPB*U rows
+    for (int64_t base = (int64_t)blockIdx.x * (RPB * U); base < n; base += (int64_t)gridDim.x * (RPB * U)) {
+        int64_t id[U];
+        int64_t row[U];
+#pragma unroll
+        for (int p = 0; p < U; ++p) {
+            row[p] = base + p * RPB + sub;
+            id[p] = (row[p] < n) ? (int64_t)ids[row[p]] : 0;
+        }
+        for (int c = lane; c < cpr; c += LPR) {
+            float v[U][V];
+#pragma unroll
+            for (int p = 0; p < U; ++p) {
+                const bool ok = (id[p] >= 0) && (id[p] < rows);
+                if (ok) {
+                    vload<V>(v[p], table + id[p] * k + c * V);
+                } else {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) v[p][x] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < U; ++p) {
+                if (row[p] < n) {
+                    float* dst = out + row[p] * k + c * V;
+                    if constexpr (V == 4) {
+                        typedef float f4 __attribute__((ext_vector_type(4)));
+                        f4 t = {v[p][0], v[p][1], v[p][2], v[p][3]};
+                        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst));
+                    } else if constexpr (V == 2) {
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        f2 t = {v[p][0], v[p][1]};
+                        __builtin_nontemporal_store(t, reinterpret_cast<f2*>(dst));
+                    } else {
+                        __builtin_nontemporal_store(v[p][0], dst);
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int p = 0; p < U; ++p)
+                if (row[p] < n && (id[p] < 0 || id[p] >= rows)) ++bad;
+        }
+    }
+    if (oob_count != nullptr && bad) atomicAdd(oob_count, bad);
+}
+
+template <int V, int LPR, typename IdT>
+static int launch_gather(const float* table, int64_t rows, int k, const IdT* ids, int64_t n, float* out,
+                         int* oob_count, hipStream_t st) {
+    constexpr int U = 4;
+    constexpr int RPB = (64 / LPR) * 4;
+    int grid = grid_for(n, 1, RPB * U);
+    hipLaunchKernelGGL((gather_kernel<V, LPR, U, IdT>), dim3(grid), dim3(256), 0, st, table, rows, k, ids, n,
+                       out, oob_count);
+    return 0;
+}
+
+template <typename IdT>
+static int dispatch_gather(const float* table, int64_t rows, int k, const IdT* ids, int64_t n, float* out,
+                           int* oob, hipStream_t st) {
+    RowShape s = row_shape(k);
+#define DR_G(V_, L_) \
+    if (s.V == V_ && s.LPR == L_) return launch_gather<V_, L_, IdT>(table, rows, k, ids, n, out, oob, st);
+    DR_G(4, 1) DR_G(4, 2) DR_G(4, 4) DR_G(4, 8) DR_G(4, 16) DR_G(4, 32) DR_G(4, 64)
+    DR_G(2, 1) DR_G(2, 2) DR_G(2, 4) DR_G(2, 8) DR_G(2, 16) DR_G(2, 32) DR_G(2, 64)
+    DR_G(1, 1) DR_G(1, 2) DR_G(1, 4) DR_G(1, 8) DR_G(1, 16) DR_G(1, 32) DR_G(1, 64)
+#undef DR_G
+    return -1;
+}
+
+}  // namespace dr
+
+extern "C" int32_t dr_gather_f32(const float* table, int64_t rows, int32_t k, const void* ids, int64_t n,
+                                 int32_t id_bits, float* out, int32_t oob_policy, int32_t* oob_count,
+                                 void* stream) {
+    DR_REQUIRE(rows >= 0 && k >= 1 && n >= 0, "dr_gather_f32: bad sizes rows=%lld k=%d n=%lld",
+               (long long)rows, k, (long long)n);
+    DR_REQUIRE(id_bits == 32 || id_bits == 64, "dr_gather_f32: id_bits must be 32 or 64, got %d", id_bits);
+    DR_REQUIRE(oob_policy == DR_OOB_ZERO || oob_policy == DR_OOB_ERROR, "dr_gather_f32: bad oob_policy %d",
+               oob_policy);
+    DR_REQUIRE(oob_policy != DR_OOB_ERROR || oob_count != nullptr,
+               "dr_gather_f32: DR_OOB_ERROR needs an oob_count word");
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(table != nullptr || rows == 0, "dr_gather_f32: table is NULL");
+    DR_REQUIRE(ids != nullptr && out != nullptr, "dr_gather_f32: ids/out is NULL");
+    DR_REQUIRE(((uintptr_t)table % 16 == 0) && ((uintptr_t)out % 16 == 0),
+               "dr_gather_f32: table/out must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = (id_bits == 32)
+                 ? dr::dispatch_gather<int32_t>(table, rows, k, (const int32_t*)ids, n, out, oob_count, st)
+                 : dr::dispatch_gather<int64_t>(table, rows, k, (const int64_t*)ids, n, out, oob_count, st);
+    DR_REQUIRE(rc == 0, "dr_gather_f32: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("dr_gather_f32");
+    return DR_OK;
+}

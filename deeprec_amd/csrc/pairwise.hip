@@ -1,0 +1,591 @@
+// K3/K4 (+K5 orchestration): per-sample interaction + loss kernels and the fused training steps.
+//
+// One sub-wave of LPR lanes owns one sample: it reads the sample's embedding rows as V-float
+// vectors, reduces the dot products with an xor butterfly inside the sub-wave, evaluates the
+// loss derivative once and writes the per-sample gradient seed g[b] plus the "stash" row that
+// the P-side update sums (so table rows are only ever re-read in their pre-step state:
+// Q is updated first from (g, P_old), P afterwards from the stash -- see DESIGN.md).
+#include "dr_common.h"
+
+namespace dr {
+
+int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
+               const int32_t* src_idx, const float* coef, int64_t n, void* plan, int kind, const dr_opt_params* opt,
+               hipStream_t st);
+int check_opt(const dr_opt_params* opt, const float* slot0, const float* slot1, const char* who);
+constexpr int KIND_ACC = -1;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- BPR forward (bprmf.py:84-92,118-119) ------------------------------------------------
+template <int V, int LPR>
+__global__ __launch_bounds__(256) void bpr_forward_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                          int64_t nu, int64_t ni, int k,
+                                                          const int32_t* __restrict__ u, const int32_t* __restrict__ i,
+                                                          const int32_t* __restrict__ j, int64_t B,
+                                                          float* __restrict__ g_out, float* __restrict__ loss_b,
+                                                          float* __restrict__ stash) {
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+    const int cpr = k / V;
+    const int64_t iters = (B + SPB - 1) / SPB;
+    for (int64_t it = blockIdx.x; it < iters; it += gridDim.x) {
+        const int64_t b = it * SPB + sub;
+        const bool live = b < B;
+        int64_t iu = 0, ii = 0, ij = 0;
+        bool ok = false;
+        if (live) {
+            iu = u[b]; ii = i[b]; ij = j[b];
+            ok = iu >= 0 && iu < nu && ii >= 0 && ii < ni && ij >= 0 && ij < ni;
+        }
+        float xui = 0.0f, xuj = 0.0f;
+        float d0[V];
+#pragma unroll
+        for (int x = 0; x < V; ++x) d0[x] = 0.0f;
+        if (ok) {
+            for (int c = lane; c < cpr; c += LPR) {
+                float pu[V], qi[V], qj[V];
+                vload<V>(pu, P + iu * k + c * V);
+                vload<V>(qi, Q + ii * k + c * V);
+                vload<V>(qj, Q + ij * k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) {
+                    xui = xui + pu[x] * qi[x];
+                    xuj = xuj + pu[x] * qj[x];
+                }
+                if (c == lane) {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) d0[x] = qi[x] - qj[x];
+                }
+            }
+        }
+        xui = subwave_sum<LPR>(xui);
+        xuj = subwave_sum<LPR>(xuj);
+        float g = 0.0f, l = 0.0f;
+        if (ok) {
+            const float s = sigmoidf_(xui - xuj);
+            l = -logf(s);
+            g = -(1.0f - s);
+        }
+        if (live) {
+            if (lane == 0) {
+                g_out[b] = g;
+                loss_b[b] = l;
+            }
+            for (int c = lane; c < cpr; c += LPR) {
+                float d[V];
+                if (c == lane) {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) d[x] = d0[x];
+                } else if (ok) {
+                    float qi[V], qj[V];
+                    vload<V>(qi, Q + ii * k + c * V);
+                    vload<V>(qj, Q + ij * k + c * V);
+#pragma unroll
+                    for (int x = 0; x < V; ++x) d[x] = qi[x] - qj[x];
+                } else {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) d[x] = 0.0f;
+                }
+#pragma unroll
+                for (int x = 0; x < V; ++x) d[x] = g * d[x];
+                vstore<V>(stash + b * k + c * V, d);
+            }
+        }
+    }
+}
+
+// idsQ = [i ; j], coefQ = [g ; -g], srcQ = [u ; u]
+__global__ __launch_bounds__(256) void bpr_qlists_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
+                                                         const int32_t* __restrict__ j, const float* __restrict__ g,
+                                                         int64_t B, int32_t* __restrict__ idsQ,
+                                                         float* __restrict__ coefQ, int32_t* __restrict__ srcQ) {
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+        const float gb = g[b];
+        idsQ[b] = i[b];
+        idsQ[B + b] = j[b];
+        coefQ[b] = gb;
+        coefQ[B + b] = -gb;
+        srcQ[b] = u[b];
+        srcQ[B + b] = u[b];
+    }
+}
+
+// ---- pointwise forward: GMF BCE (gmf.py:66-75) / MF squared error (mf.py:50-55,96-97) ----
+template <int V, int LPR, bool SQ>
+__global__ __launch_bounds__(256) void pointwise_forward_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, const float* __restrict__ BU,
+    const float* __restrict__ BI, float mu, int64_t nu, int64_t ni, int k, const int32_t* __restrict__ u,
+    const int32_t* __restrict__ i, const float* __restrict__ y, int64_t B, float* __restrict__ g_out,
+    float* __restrict__ loss_b, float* __restrict__ pred, float* __restrict__ stash) {
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+    const int cpr = k / V;
+    const int64_t iters = (B + SPB - 1) / SPB;
+    for (int64_t it = blockIdx.x; it < iters; it += gridDim.x) {
+        const int64_t b = it * SPB + sub;
+        const bool live = b < B;
+        int64_t iu = 0, ii = 0;
+        bool ok = false;
+        if (live) {
+            iu = u[b]; ii = i[b];
+            ok = iu >= 0 && iu < nu && ii >= 0 && ii < ni;
+        }
+        float z = 0.0f;
+        float q0[V];
+#pragma unroll
+        for (int x = 0; x < V; ++x) q0[x] = 0.0f;
+        if (ok) {
+            for (int c = lane; c < cpr; c += LPR) {
+                float pu[V], qi[V];
+                vload<V>(pu, P + iu * k + c * V);
+                vload<V>(qi, Q + ii * k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) z = z + pu[x] * qi[x];
+                if (c == lane) {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) q0[x] = qi[x];
+                }
+            }
+        }
+        z = subwave_sum<LPR>(z);
+        float g = 0.0f, l = 0.0f, out = 0.0f;
+        if (ok) {
+            if constexpr (SQ) {
+                z = z + BU[iu] + BI[ii] + mu;
+                out = z;
+                if (y) {
+                    const float d = y[b] - z;
+                    l = d * d;
+                    g = -2.0f * d;
+                }
+            } else {
+                const float p = sigmoidf_(z);
+                out = p;
+                if (y) {
+                    const float yy = y[b];
+                    const float e = 1e-10f;
+                    l = -(yy * logf(p + e) + (1.0f - yy) * logf(1.0f - p + e));
+                    const float dp = -(yy / (p + e)) + (1.0f - yy) / (1.0f - p + e);
+                    g = dp * (p * (1.0f - p));
+                }
+            }
+        }
+        if (live) {
+            if (lane == 0) {
+                if (g_out) g_out[b] = g;
+                if (loss_b) loss_b[b] = l;
+                if (pred) pred[b] = out;
+            }
+            if (stash)
+                for (int c = lane; c < cpr; c += LPR) {
+                    float d[V];
+                    if (c == lane) {
+#pragma unroll
+                        for (int x = 0; x < V; ++x) d[x] = q0[x];
+                    } else if (ok) {
+                        vload<V>(d, Q + ii * k + c * V);
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < V; ++x) d[x] = 0.0f;
+                    }
+#pragma unroll
+                    for (int x = 0; x < V; ++x) d[x] = g * d[x];
+                    vstore<V>(stash + b * k + c * V, d);
+                }
+        }
+    }
+}
+
+// ---- CML hinge forward (cml.py:68-77): stash[b] = dL/dq_i, stash[B+b] = dL/dq_j ----------
+template <int V, int LPR>
+__global__ __launch_bounds__(256) void hinge_forward_kernel(
+    const float* __restrict__ P, const float* __restrict__ Q, int64_t nu, int64_t ni, int k,
+    const int32_t* __restrict__ u, const int32_t* __restrict__ i, const int32_t* __restrict__ j,
+    const uint8_t* __restrict__ mask_pos, const uint8_t* __restrict__ mask_neg, float keep, float margin, int64_t B,
+    float* __restrict__ loss_b, float* __restrict__ stash) {
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+    const int cpr = k / V;
+    const float sc = 1.0f / keep;
+    const int64_t iters = (B + SPB - 1) / SPB;
+    for (int64_t it = blockIdx.x; it < iters; it += gridDim.x) {
+        const int64_t b = it * SPB + sub;
+        const bool live = b < B;
+        int64_t iu = 0, ii = 0, ij = 0;
+        bool ok = false;
+        if (live) {
+            iu = u[b]; ii = i[b]; ij = j[b];
+            ok = iu >= 0 && iu < nu && ii >= 0 && ii < ni && ij >= 0 && ij < ni;
+        }
+        float ap = 0.0f, an = 0.0f;
+        if (ok) {
+            for (int c = lane; c < cpr; c += LPR) {
+                float pu[V], qi[V], qj[V];
+                vload<V>(pu, P + iu * k + c * V);
+                vload<V>(qi, Q + ii * k + c * V);
+                vload<V>(qj, Q + ij * k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) {
+                    const float mp = (mask_pos ? (float)mask_pos[b * k + c * V + x] : 1.0f) * sc;
+                    const float mn = (mask_neg ? (float)mask_neg[b * k + c * V + x] : 1.0f) * sc;
+                    const float dp = pu[x] - qi[x], dn = pu[x] - qj[x];
+                    ap = ap + (dp * dp) * mp;
+                    an = an + (dn * dn) * mn;
+                }
+            }
+        }
+        ap = subwave_sum<LPR>(ap);
+        an = subwave_sum<LPR>(an);
+        const float a = ap - an + margin;
+        const float act = (ok && a >= 0.0f) ? 1.0f : 0.0f;
+        if (live) {
+            if (lane == 0) loss_b[b] = ok ? fmaxf(a, 0.0f) : 0.0f;
+            for (int c = lane; c < cpr; c += LPR) {
+                float gi[V], gj[V];
+                if (ok) {
+                    float pu[V], qi[V], qj[V];
+                    vload<V>(pu, P + iu * k + c * V);
+                    vload<V>(qi, Q + ii * k + c * V);
+                    vload<V>(qj, Q + ij * k + c * V);
+#pragma unroll
+                    for (int x = 0; x < V; ++x) {
+                        const float mp = (mask_pos ? (float)mask_pos[b * k + c * V + x] : 1.0f) * sc;
+                        const float mn = (mask_neg ? (float)mask_neg[b * k + c * V + x] : 1.0f) * sc;
+                        gi[x] = -(act * ((2.0f * mp) * (pu[x] - qi[x])));
+                        gj[x] = act * ((2.0f * mn) * (pu[x] - qj[x]));
+                    }
+                } else {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) gi[x] = gj[x] = 0.0f;
+                }
+                vstore<V>(stash + b * k + c * V, gi);
+                vstore<V>(stash + (B + b) * k + c * V, gj);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hinge_lists_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
+                                                          const int32_t* __restrict__ j, int64_t B,
+                                                          int32_t* __restrict__ idsP, int32_t* __restrict__ idsQ,
+                                                          float* __restrict__ coefP) {
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+        idsP[b] = u[b];
+        idsP[B + b] = u[b];
+        idsQ[b] = i[b];
+        idsQ[B + b] = j[b];
+        coefP[b] = -1.0f;
+        coefP[B + b] = -1.0f;
+    }
+}
+
+// ---- per-pair k-ordered fmaf chain (bprmf.py:168-173) --------------------------------------
+__global__ __launch_bounds__(256) void pair_dot_kernel(const float* __restrict__ A, int64_t rowsA,
+                                                       const float* __restrict__ Bm, int64_t rowsB, int k,
+                                                       const int32_t* __restrict__ ai, const int32_t* __restrict__ bi,
+                                                       int64_t n, float* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t a = ai[e], b = bi[e];
+        float acc = 0.0f;
+        if (a >= 0 && a < rowsA && b >= 0 && b < rowsB) {
+            const float* pa = A + a * k;
+            const float* pb = Bm + b * k;
+            for (int c = 0; c < k; ++c) acc = __builtin_fmaf(pa[c], pb[c], acc);
+        }
+        out[e] = acc;
+    }
+}
+
+#define DR_SHAPE_DISPATCH(MACRO)                                                                     \
+    MACRO(4, 1) MACRO(4, 2) MACRO(4, 4) MACRO(4, 8) MACRO(4, 16) MACRO(4, 32) MACRO(4, 64)           \
+    MACRO(2, 1) MACRO(2, 2) MACRO(2, 4) MACRO(2, 8) MACRO(2, 16) MACRO(2, 32) MACRO(2, 64)           \
+    MACRO(1, 1) MACRO(1, 2) MACRO(1, 4) MACRO(1, 8) MACRO(1, 16) MACRO(1, 32) MACRO(1, 64)
+
+// workspace layout of the fused steps
+struct StepLayout {
+    int64_t g, loss_b, stash, idsA, idsB, coef, src, planA, planB, gdenseP, gdenseQ, total, plan_bytesA, plan_bytesB;
+};
+}  // namespace dr
+
+using namespace dr;
+
+extern "C" int64_t dr_segment_plan_bytes(int64_t n);
+extern "C" int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, int64_t rows, void* plan,
+                                   int64_t plan_bytes, void* stream);
+
+namespace dr {
+// stash_rows: B for BPR / pointwise, 2B for hinge.  dense tables only in DR_REG_DENSE.
+static int step_layout(int64_t B, int k, int64_t stash_rows, int64_t nu, int64_t ni, bool dense, StepLayout* L) {
+    int64_t BB = B > 0 ? B : 1;
+    int64_t pa = dr_segment_plan_bytes(2 * BB), pb = dr_segment_plan_bytes(2 * BB);
+    if (pa < 0 || pb < 0) return -1;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    L->g = take(BB * 4);
+    L->loss_b = take(BB * 4);
+    L->stash = take((stash_rows > 0 ? stash_rows : 1) * (int64_t)k * 4);
+    L->idsA = take(2 * BB * 4);
+    L->idsB = take(2 * BB * 4);
+    L->coef = take(2 * BB * 4);
+    L->src = take(2 * BB * 4);
+    L->planA = take(pa);
+    L->planB = take(pb);
+    L->plan_bytesA = pa;
+    L->plan_bytesB = pb;
+    L->gdenseP = dense ? take(nu * (int64_t)k * 4) : 0;
+    L->gdenseQ = dense ? take(ni * (int64_t)k * 4) : 0;
+    L->total = off;
+    return 0;
+}
+
+// One table's update from a contribution list, in either sparse (touched / none) or dense mode.
+static int table_update(float* T, float* s0, float* s1, int64_t rows, int k, const int32_t* ids, int64_t n,
+                        const float* src, int64_t src_rows, const int32_t* src_idx, const float* coef, void* plan,
+                        int64_t plan_bytes, float* gdense, const dr_opt_params* opt, hipStream_t st) {
+    int rc = dr_segment_plan(ids, n, 32, rows, plan, plan_bytes, st);
+    if (rc != DR_OK) return rc;
+    if (opt->reg_mode == DR_REG_DENSE) {
+        DR_HIP(hipMemsetAsync(gdense, 0, (size_t)rows * k * 4, st));
+        rc = seg_launch(gdense, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, KIND_ACC, nullptr, st);
+        if (rc != DR_OK) return rc;
+        return dr_dense_update_f32(T, s0, s1, gdense, rows * (int64_t)k, opt, st);
+    }
+    return seg_launch(T, s0, s1, rows, k, src, src_rows, src_idx, coef, n, plan, opt->kind, opt, st);
+}
+}  // namespace dr
+
+extern "C" int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t num_user, int64_t num_item, int32_t k,
+                                      const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, float* g_out,
+                                      float* loss_b, float* stash, void* stream) {
+    DR_REQUIRE(num_user >= 0 && num_item >= 0 && k >= 1 && B >= 0, "dr_bpr_forward_f32: bad sizes");
+    if (B == 0) return DR_OK;
+    DR_REQUIRE(P && Q && u && i && j && g_out && loss_b && stash, "dr_bpr_forward_f32: NULL pointer");
+    RowShape s = row_shape(k);
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+#define DR_F(V_, L_)                                                                                                \
+    if (!ok && s.V == V_ && s.LPR == L_) {                                                                          \
+        hipLaunchKernelGGL((bpr_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, st, P, Q,    \
+                           num_user, num_item, k, u, i, j, B, g_out, loss_b, stash);                                \
+        ok = true;                                                                                                  \
+    }
+    DR_SHAPE_DISPATCH(DR_F)
+#undef DR_F
+    DR_REQUIRE(ok, "dr_bpr_forward_f32: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("dr_bpr_forward_f32");
+    return DR_OK;
+}
+
+extern "C" int64_t dr_pairwise_step_bytes(int64_t B, int32_t k, int64_t num_user, int64_t num_item,
+                                          int32_t reg_mode) {
+    if (B < 0 || k < 1) return DR_ERR_ARG;
+    StepLayout L;
+    if (step_layout(B, k, 2 * B, num_user, num_item, reg_mode == DR_REG_DENSE, &L) != 0) return DR_ERR_LAUNCH;
+    return L.total;
+}
+
+extern "C" int32_t dr_bpr_step_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q, float* Qslot0,
+                                   float* Qslot1, int64_t num_item, int32_t k, const int32_t* u, const int32_t* i,
+                                   const int32_t* j, int64_t B, const dr_opt_params* opt, float* loss_out, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+    DR_REQUIRE(num_user >= 0 && num_item >= 0 && k >= 1 && B >= 0, "dr_bpr_step_f32: bad sizes");
+    int rc = check_opt(opt, Pslot0, Pslot1, "dr_bpr_step_f32(P)");
+    if (rc != DR_OK) return rc;
+    rc = check_opt(opt, Qslot0, Qslot1, "dr_bpr_step_f32(Q)");
+    if (rc != DR_OK) return rc;
+    DR_REQUIRE(P && Q && ws && ((uintptr_t)ws % 256 == 0), "dr_bpr_step_f32: NULL / misaligned pointer");
+    DR_REQUIRE(B == 0 || (u && i && j), "dr_bpr_step_f32: id pointer is NULL");
+    StepLayout L;
+    if (step_layout(B, k, 2 * B, num_user, num_item, opt->reg_mode == DR_REG_DENSE, &L) != 0) return DR_ERR_LAUNCH;
+    if (ws_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_bpr_step_f32: workspace %lld < required %lld", (long long)ws_bytes,
+                (long long)L.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)ws;
+    float* g = (float*)(base + L.g);
+    float* loss_b = (float*)(base + L.loss_b);
+    float* stash = (float*)(base + L.stash);
+    int32_t* idsQ = (int32_t*)(base + L.idsA);
+    float* coefQ = (float*)(base + L.coef);
+    int32_t* srcQ = (int32_t*)(base + L.src);
+    if (B > 0) {
+        rc = dr_bpr_forward_f32(P, Q, num_user, num_item, k, u, i, j, B, g, loss_b, stash, st);
+        if (rc != DR_OK) return rc;
+        hipLaunchKernelGGL(bpr_qlists_kernel, dim3(grid_for(B, 256)), dim3(256), 0, st, u, i, j, g, B, idsQ, coefQ, srcQ);
+        DR_CHECK_LAUNCH("bpr_qlists_kernel");
+    }
+    if (B > 0 || opt->reg_mode == DR_REG_DENSE) {
+        // Q first: its gradient needs the pre-step P rows.  P afterwards from the stash.
+        rc = table_update(Q, Qslot0, Qslot1, num_item, k, idsQ, 2 * B, P, num_user, srcQ, coefQ, base + L.planA,
+                          L.plan_bytesA, (float*)(base + L.gdenseQ), opt, st);
+        if (rc != DR_OK) return rc;
+        rc = table_update(P, Pslot0, Pslot1, num_user, k, u, B, stash, B, nullptr, nullptr, base + L.planB,
+                          L.plan_bytesB, (float*)(base + L.gdenseP), opt, st);
+        if (rc != DR_OK) return rc;
+    }
+    if (loss_out) return dr_sum_f32(loss_b, B, loss_out, st);
+    return DR_OK;
+}
+
+extern "C" int32_t dr_pointwise_forward_f32(const float* P, const float* Q, const float* BU, const float* BI, float mu,
+                                            int64_t num_user, int64_t num_item, int32_t k, int32_t loss_kind,
+                                            const int32_t* u, const int32_t* i, const float* y, int64_t B,
+                                            float* g_out, float* loss_b, float* pred, float* stash, void* stream) {
+    DR_REQUIRE(num_user >= 0 && num_item >= 0 && k >= 1 && B >= 0, "dr_pointwise_forward_f32: bad sizes");
+    DR_REQUIRE(loss_kind == 0 || loss_kind == 1, "dr_pointwise_forward_f32: loss_kind must be 0 (bce) or 1 (sq)");
+    DR_REQUIRE(loss_kind == 0 || (BU && BI), "dr_pointwise_forward_f32: squared-error kind needs bias vectors");
+    if (B == 0) return DR_OK;
+    DR_REQUIRE(P && Q && u && i, "dr_pointwise_forward_f32: NULL pointer");
+    DR_REQUIRE(y || (!g_out && !loss_b && !stash), "dr_pointwise_forward_f32: labels needed for gradients");
+    RowShape s = row_shape(k);
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+#define DR_F(V_, L_)                                                                                                 \
+    if (!ok && s.V == V_ && s.LPR == L_) {                                                                           \
+        if (loss_kind == 1)                                                                                          \
+            hipLaunchKernelGGL((pointwise_forward_kernel<V_, L_, true>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, \
+                               st, P, Q, BU, BI, mu, num_user, num_item, k, u, i, y, B, g_out, loss_b, pred, stash); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((pointwise_forward_kernel<V_, L_, false>), dim3(grid_for(B, 1, 256 / L_)), dim3(256),  \
+                               0, st, P, Q, BU, BI, mu, num_user, num_item, k, u, i, y, B, g_out, loss_b, pred,      \
+                               stash);                                                                               \
+        ok = true;                                                                                                   \
+    }
+    DR_SHAPE_DISPATCH(DR_F)
+#undef DR_F
+    DR_REQUIRE(ok, "dr_pointwise_forward_f32: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("dr_pointwise_forward_f32");
+    return DR_OK;
+}
+
+// GMF (loss_kind 0) / biased MF (loss_kind 1) training step.  Bias vectors are [rows] tables (k=1).
+extern "C" int32_t dr_pointwise_step_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q,
+                                         float* Qslot0, float* Qslot1, int64_t num_item, int32_t k, float* BU,
+                                         float* BUslot0, float* BUslot1, float* BI, float* BIslot0, float* BIslot1,
+                                         float mu, int32_t loss_kind, const int32_t* u, const int32_t* i,
+                                         const float* y, int64_t B, const dr_opt_params* opt, float* loss_out,
+                                         void* ws, int64_t ws_bytes, void* stream) {
+    DR_REQUIRE(num_user >= 0 && num_item >= 0 && k >= 1 && B >= 0, "dr_pointwise_step_f32: bad sizes");
+    int rc = check_opt(opt, Pslot0, Pslot1, "dr_pointwise_step_f32(P)");
+    if (rc != DR_OK) return rc;
+    rc = check_opt(opt, Qslot0, Qslot1, "dr_pointwise_step_f32(Q)");
+    if (rc != DR_OK) return rc;
+    if (loss_kind == 1) {
+        rc = check_opt(opt, BUslot0, BUslot1, "dr_pointwise_step_f32(BU)");
+        if (rc != DR_OK) return rc;
+        rc = check_opt(opt, BIslot0, BIslot1, "dr_pointwise_step_f32(BI)");
+        if (rc != DR_OK) return rc;
+    }
+    DR_REQUIRE(P && Q && ws && ((uintptr_t)ws % 256 == 0), "dr_pointwise_step_f32: NULL / misaligned pointer");
+    DR_REQUIRE(B == 0 || (u && i && y), "dr_pointwise_step_f32: id / label pointer is NULL");
+    StepLayout L;
+    if (step_layout(B, k, 2 * B, num_user, num_item, opt->reg_mode == DR_REG_DENSE, &L) != 0) return DR_ERR_LAUNCH;
+    if (ws_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_pointwise_step_f32: workspace %lld < required %lld", (long long)ws_bytes,
+                (long long)L.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)ws;
+    float* g = (float*)(base + L.g);
+    float* loss_b = (float*)(base + L.loss_b);
+    float* stash = (float*)(base + L.stash);
+    if (B > 0) {
+        rc = dr_pointwise_forward_f32(P, Q, BU, BI, mu, num_user, num_item, k, loss_kind, u, i, y, B, g, loss_b,
+                                      nullptr, stash, st);
+        if (rc != DR_OK) return rc;
+    }
+    if (B > 0 || opt->reg_mode == DR_REG_DENSE) {
+        // bias vectors first (they only need g), then Q from (g, P_old), then P from the stash
+        if (loss_kind == 1) {
+            rc = table_update(BU, BUslot0, BUslot1, num_user, 1, u, B, g, B, nullptr, nullptr, base + L.planA,
+                              L.plan_bytesA, (float*)(base + L.gdenseP), opt, st);
+            if (rc != DR_OK) return rc;
+            rc = table_update(BI, BIslot0, BIslot1, num_item, 1, i, B, g, B, nullptr, nullptr, base + L.planA,
+                              L.plan_bytesA, (float*)(base + L.gdenseQ), opt, st);
+            if (rc != DR_OK) return rc;
+        }
+        rc = table_update(Q, Qslot0, Qslot1, num_item, k, i, B, P, num_user, u, g, base + L.planA, L.plan_bytesA,
+                          (float*)(base + L.gdenseQ), opt, st);
+        if (rc != DR_OK) return rc;
+        rc = table_update(P, Pslot0, Pslot1, num_user, k, u, B, stash, B, nullptr, nullptr, base + L.planB,
+                          L.plan_bytesB, (float*)(base + L.gdenseP), opt, st);
+        if (rc != DR_OK) return rc;
+    }
+    if (loss_out) return dr_sum_f32(loss_b, B, loss_out, st);
+    return DR_OK;
+}
+
+// CML step (cml.py:72-81,120): hinge on squared distances, sparse Adagrad, whole-table row-norm clip.
+extern "C" int32_t dr_hinge_step_f32(float* P, float* Pacc, int64_t num_user, float* Q, float* Qacc, int64_t num_item,
+                                     int32_t k, const int32_t* u, const int32_t* i, const int32_t* j,
+                                     const uint8_t* mask_pos, const uint8_t* mask_neg, float keep, float margin,
+                                     float clip, int64_t B, const dr_opt_params* opt, float* loss_out, void* ws,
+                                     int64_t ws_bytes, void* stream) {
+    DR_REQUIRE(num_user >= 0 && num_item >= 0 && k >= 1 && B >= 0, "dr_hinge_step_f32: bad sizes");
+    DR_REQUIRE(keep > 0.0f && keep <= 1.0f, "dr_hinge_step_f32: keep must be in (0,1]");
+    int rc = check_opt(opt, Pacc, Pacc, "dr_hinge_step_f32(P)");
+    if (rc != DR_OK) return rc;
+    rc = check_opt(opt, Qacc, Qacc, "dr_hinge_step_f32(Q)");
+    if (rc != DR_OK) return rc;
+    DR_REQUIRE(opt->reg_mode == DR_REG_NONE, "dr_hinge_step_f32: CML has no L2 term (cml.py:77), use DR_REG_NONE");
+    DR_REQUIRE(P && Q && ws && ((uintptr_t)ws % 256 == 0), "dr_hinge_step_f32: NULL / misaligned pointer");
+    DR_REQUIRE(B == 0 || (u && i && j), "dr_hinge_step_f32: id pointer is NULL");
+    StepLayout L;
+    if (step_layout(B, k, 2 * B, num_user, num_item, false, &L) != 0) return DR_ERR_LAUNCH;
+    if (ws_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_hinge_step_f32: workspace %lld < required %lld", (long long)ws_bytes,
+                (long long)L.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)ws;
+    float* loss_b = (float*)(base + L.loss_b);
+    float* stash = (float*)(base + L.stash);
+    int32_t* idsP = (int32_t*)(base + L.idsA);
+    int32_t* idsQ = (int32_t*)(base + L.idsB);
+    float* coefP = (float*)(base + L.coef);
+    if (B > 0) {
+        RowShape s = row_shape(k);
+        bool ok = false;
+#define DR_F(V_, L_)                                                                                              \
+    if (!ok && s.V == V_ && s.LPR == L_) {                                                                        \
+        hipLaunchKernelGGL((hinge_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, st, P, Q, \
+                           num_user, num_item, k, u, i, j, mask_pos, mask_neg, keep, margin, B, loss_b, stash);   \
+        ok = true;                                                                                                \
+    }
+        DR_SHAPE_DISPATCH(DR_F)
+#undef DR_F
+        DR_REQUIRE(ok, "dr_hinge_step_f32: unsupported k=%d", k);
+        DR_CHECK_LAUNCH("hinge_forward_kernel");
+        hipLaunchKernelGGL(hinge_lists_kernel, dim3(grid_for(B, 256)), dim3(256), 0, st, u, i, j, B, idsP, idsQ, coefP);
+        DR_CHECK_LAUNCH("hinge_lists_kernel");
+        // both updates read only the stash, so their order is free
+        rc = table_update(Q, Qacc, nullptr, num_item, k, idsQ, 2 * B, stash, 2 * B, nullptr, nullptr, base + L.planA,
+                          L.plan_bytesA, nullptr, opt, st);
+        if (rc != DR_OK) return rc;
+        rc = table_update(P, Pacc, nullptr, num_user, k, idsP, 2 * B, stash, 2 * B, nullptr, coefP, base + L.planB,
+                          L.plan_bytesB, nullptr, opt, st);
+        if (rc != DR_OK) return rc;
+    }
+    if (clip > 0.0f) {
+        rc = dr_rownorm_clip_f32(P, num_user, k, clip, st);
+        if (rc != DR_OK) return rc;
+        rc = dr_rownorm_clip_f32(Q, num_item, k, clip, st);
+        if (rc != DR_OK) return rc;
+    }
+    if (loss_out) return dr_sum_f32(loss_b, B, loss_out, st);
+    return DR_OK;
+}
+
+extern "C" int32_t dr_pair_dot_f32(const float* A, int64_t rowsA, const float* B, int64_t rowsB, int32_t k,
+                                   const int32_t* a_idx, const int32_t* b_idx, int64_t n, float* out, void* stream) {
+    DR_REQUIRE(rowsA >= 0 && rowsB >= 0 && k >= 1 && n >= 0, "dr_pair_dot_f32: bad sizes");
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(A && B && a_idx && b_idx && out, "dr_pair_dot_f32: NULL pointer");
+    hipLaunchKernelGGL(pair_dot_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, A, rowsA, B, rowsB, k,
+                       a_idx, b_idx, n, out);
+    DR_CHECK_LAUNCH("dr_pair_dot_f32");
+    return DR_OK;
+}

@@ -1,0 +1,474 @@
+// K2 / K5: segment plan (stable sort of an id list + run boundaries), deterministic
+// sorted-segment scatter-add, and the fused "segment sum -> optimizer row update" kernel.
+//
+// HBM-bound integer/float streaming work: no MFMA.  One sub-wave of LPR lanes owns one
+// destination row (k=128: 32 lanes x float4, two rows per wavefront); contributions of a row
+// are summed in blocked position order (DR_SEG_CHUNK) so results are bit-repeatable and equal
+// to oracle/ref_ops.py:segment_sums.  The sort / scan of the plan use rocPRIM device primitives
+// (radix_sort_pairs, exclusive_scan); everything that touches table rows is hand-written.
+#include "dr_common.h"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace dr {
+
+// ---------------------------------------------------------------------------------------
+// plan layout inside the caller's workspace
+// ---------------------------------------------------------------------------------------
+struct PlanLayout {
+    int64_t hdr, keys_in, keys_out, vals_in, vals_out, flags, segidx, uniq, seg_start, temp, temp_bytes, total;
+};
+
+static int plan_layout(int64_t n, PlanLayout* L, char* err) {
+    size_t t_sort = 0, t_scan = 0;
+    int64_t nn = n > 0 ? n : 1;
+    hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, int32_t*, int32_t*>(
+        nullptr, t_sort, nullptr, nullptr, nullptr, nullptr, (size_t)nn, 0, 32, 0, false);
+    if (e != hipSuccess) {
+        snprintf(err, 512, "rocprim radix_sort size query: %s", hipGetErrorString(e));
+        return -1;
+    }
+    e = rocprim::exclusive_scan<rocprim::default_config, int32_t*, int32_t*, int32_t, rocprim::plus<int32_t>>(
+        nullptr, t_scan, nullptr, nullptr, 0, (size_t)nn, rocprim::plus<int32_t>(), 0, false);
+    if (e != hipSuccess) {
+        snprintf(err, 512, "rocprim exclusive_scan size query: %s", hipGetErrorString(e));
+        return -1;
+    }
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    L->hdr = take(256);
+    L->keys_in = take(nn * 4);
+    L->keys_out = take(nn * 4);
+    L->vals_in = take(nn * 4);
+    L->vals_out = take(nn * 4);
+    L->flags = take(nn * 4);
+    L->segidx = take(nn * 4);
+    L->uniq = take(nn * 4);
+    L->seg_start = take((nn + 1) * 4);
+    L->temp_bytes = (int64_t)(t_sort > t_scan ? t_sort : t_scan) + 256;
+    L->temp = take(L->temp_bytes);
+    L->total = off;
+    return 0;
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void plan_keys_kernel(const IdT* __restrict__ ids, int64_t n, int64_t rows,
+                                                        uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        int64_t id = (int64_t)ids[e];
+        keys[e] = (id < 0 || id >= rows) ? (uint32_t)rows : (uint32_t)id;  // out-of-range -> sentinel `rows`
+        vals[e] = (int32_t)e;
+    }
+}
+
+__global__ __launch_bounds__(256) void plan_heads_kernel(const uint32_t* __restrict__ sk, int64_t n,
+                                                         int32_t* __restrict__ flags) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+        flags[e] = (e == 0 || sk[e] != sk[e - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void plan_finalize_kernel(const uint32_t* __restrict__ sk,
+                                                            const int32_t* __restrict__ flags,
+                                                            const int32_t* __restrict__ segidx, int64_t n,
+                                                            int32_t* __restrict__ uniq, int32_t* __restrict__ seg_start,
+                                                            int32_t* __restrict__ hdr) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        if (flags[e]) {
+            uniq[segidx[e]] = (int32_t)sk[e];
+            seg_start[segidx[e]] = (int32_t)e;
+        }
+        if (e == n - 1) {
+            int32_t ns = segidx[e] + flags[e];
+            hdr[0] = ns;
+            seg_start[ns] = (int32_t)n;
+        }
+    }
+}
+
+__global__ void plan_empty_kernel(int32_t* hdr, int32_t* seg_start) {
+    hdr[0] = 0;
+    seg_start[0] = 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// segment sum (+ optimizer application)
+// ---------------------------------------------------------------------------------------
+constexpr int KIND_ACC = -1;
+
+struct SegArgs {
+    float* table;
+    float* slot0;
+    float* slot1;
+    int64_t rows;
+    int k;
+    const float* src;
+    int64_t src_rows;
+    const int32_t* src_idx;
+    const float* coef;
+    const int32_t* sorted_pos;
+    const int32_t* uniq;
+    const int32_t* seg_start;
+    const int32_t* nseg;
+    int kind;
+    OptP opt;
+};
+
+template <int V, int LPR>
+__global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
+    constexpr int SPB = 256 / LPR;  // segments per block pass
+    const int sub = threadIdx.x / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int cpr = a.k / V;
+    const int nseg = *a.nseg;
+    for (int s = blockIdx.x * SPB + sub; s < nseg; s += gridDim.x * SPB) {
+        const uint32_t r = (uint32_t)a.uniq[s];
+        if ((int64_t)r >= a.rows) continue;  // sentinel segment of out-of-range ids
+        const int b = a.seg_start[s], e = a.seg_start[s + 1];
+        for (int c = lane; c < cpr; c += LPR) {
+            float tot[V];
+#pragma unroll
+            for (int x = 0; x < V; ++x) tot[x] = 0.0f;
+            for (int c0 = b; c0 < e; c0 += DR_SEG_CHUNK) {
+                float acc[V];
+#pragma unroll
+                for (int x = 0; x < V; ++x) acc[x] = 0.0f;
+                const int ce = (c0 + DR_SEG_CHUNK < e) ? c0 + DR_SEG_CHUNK : e;
+                for (int y = c0; y < ce; ++y) {
+                    const int p = a.sorted_pos[y];
+                    const int64_t si = a.src_idx ? (int64_t)a.src_idx[p] : (int64_t)p;
+                    if (si < 0 || si >= a.src_rows) continue;
+                    float v[V];
+                    vload<V>(v, a.src + si * a.k + c * V);
+                    if (a.coef) {
+                        const float cf = a.coef[p];
+#pragma unroll
+                        for (int x = 0; x < V; ++x) v[x] = cf * v[x];
+                    }
+#pragma unroll
+                    for (int x = 0; x < V; ++x) acc[x] = acc[x] + v[x];
+                }
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = tot[x] + acc[x];
+            }
+            const int64_t off = (int64_t)r * a.k + c * V;
+            float w[V], s0[V], s1[V];
+            vload<V>(w, a.table + off);
+            if (a.kind == KIND_ACC) {
+#pragma unroll
+                for (int x = 0; x < V; ++x) w[x] = w[x] + tot[x];
+                vstore<V>(a.table + off, w);
+                continue;
+            }
+            if (a.opt.reg_mode == DR_REG_TOUCHED) {
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = tot[x] + a.opt.reg * w[x];
+            }
+            switch (a.kind) {
+                case DR_OPT_SGD:
+#pragma unroll
+                    for (int x = 0; x < V; ++x) opt_apply<DR_OPT_SGD>(w[x], s0[x], s1[x], tot[x], a.opt);
+                    break;
+                case DR_OPT_ADAM:
+                    vload<V>(s0, a.slot0 + off);
+                    vload<V>(s1, a.slot1 + off);
+#pragma unroll
+                    for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAM>(w[x], s0[x], s1[x], tot[x], a.opt);
+                    vstore<V>(a.slot0 + off, s0);
+                    vstore<V>(a.slot1 + off, s1);
+                    break;
+                case DR_OPT_ADAGRAD:
+                    vload<V>(s0, a.slot0 + off);
+#pragma unroll
+                    for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAGRAD>(w[x], s0[x], s1[x], tot[x], a.opt);
+                    vstore<V>(a.slot0 + off, s0);
+                    break;
+                default:
+                    vload<V>(s0, a.slot0 + off);
+                    vload<V>(s1, a.slot1 + off);
+#pragma unroll
+                    for (int x = 0; x < V; ++x) opt_apply<DR_OPT_RMSPROP>(w[x], s0[x], s1[x], tot[x], a.opt);
+                    vstore<V>(a.slot0 + off, s0);
+                    vstore<V>(a.slot1 + off, s1);
+                    break;
+            }
+            vstore<V>(a.table + off, w);
+        }
+    }
+}
+
+template <int V, int LPR>
+static void launch_seg(const SegArgs& a, int64_t n, hipStream_t st) {
+    constexpr int SPB = 256 / LPR;
+    int grid = grid_for(n, 1, SPB);
+    hipLaunchKernelGGL((seg_update_kernel<V, LPR>), dim3(grid), dim3(256), 0, st, a);
+}
+
+static int dispatch_seg(const SegArgs& a, int64_t n, hipStream_t st) {
+    RowShape s = row_shape(a.k);
+#define DR_S(V_, L_)                     \
+    if (s.V == V_ && s.LPR == L_) {      \
+        launch_seg<V_, L_>(a, n, st);    \
+        return 0;                        \
+    }
+    DR_S(4, 1) DR_S(4, 2) DR_S(4, 4) DR_S(4, 8) DR_S(4, 16) DR_S(4, 32) DR_S(4, 64)
+    DR_S(2, 1) DR_S(2, 2) DR_S(2, 4) DR_S(2, 8) DR_S(2, 16) DR_S(2, 32) DR_S(2, 64)
+    DR_S(1, 1) DR_S(1, 2) DR_S(1, 4) DR_S(1, 8) DR_S(1, 16) DR_S(1, 32) DR_S(1, 64)
+#undef DR_S
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------
+// dense (whole tensor) optimizer application and row-norm clip
+// ---------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ w, float* __restrict__ s0p,
+                                                           float* __restrict__ s1p, const float* __restrict__ grad,
+                                                           int64_t count, OptP o) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        float wi = w[i];
+        float g = grad ? grad[i] : 0.0f;
+        if (o.reg_mode != DR_REG_NONE) g = g + o.reg * wi;
+        float a = 0.0f, b = 0.0f;
+        if constexpr (KIND != DR_OPT_SGD) a = s0p[i];
+        if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) b = s1p[i];
+        opt_apply<KIND>(wi, a, b, g, o);
+        w[i] = wi;
+        if constexpr (KIND != DR_OPT_SGD) s0p[i] = a;
+        if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) s1p[i] = b;
+    }
+}
+
+// one sub-wave per row: sequential-in-lane partial sums of squares, butterfly, scale
+template <int V, int LPR>
+__global__ __launch_bounds__(256) void rownorm_clip_kernel(float* __restrict__ t, int64_t rows, int k, float clip) {
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+    const int cpr = k / V;
+    const int64_t iters = (rows + RPB - 1) / RPB;
+    for (int64_t it = blockIdx.x; it < iters; it += gridDim.x) {
+        const int64_t r = it * RPB + sub;
+        float ss = 0.0f;
+        if (r < rows)
+            for (int c = lane; c < cpr; c += LPR) {
+                float v[V];
+                vload<V>(v, t + r * k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) ss = ss + v[x] * v[x];
+            }
+        ss = subwave_sum<LPR>(ss);
+        const float nrm = sqrtf(ss);
+        // [TF-ext] clip_by_norm: (t * clip) / max(norm, clip); rows with norm <= clip are left
+        // untouched, which is exact for clip = 1 (the only value the reference uses, cml.py:56).
+        if (r < rows && nrm > clip) {
+            for (int c = lane; c < cpr; c += LPR) {
+                float v[V];
+                vload<V>(v, t + r * k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) v[x] = (v[x] * clip) / nrm;
+                vstore<V>(t + r * k + c * V, v);
+            }
+        }
+    }
+}
+
+}  // namespace dr
+
+using namespace dr;
+
+extern "C" int64_t dr_segment_plan_bytes(int64_t n) {
+    if (n < 0) return DR_ERR_ARG;
+    PlanLayout L;
+    if (plan_layout(n, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    return L.total;
+}
+
+extern "C" int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, int64_t rows, void* plan,
+                                   int64_t plan_bytes, void* stream) {
+    DR_REQUIRE(n >= 0 && n < (1ll << 31) - 1, "dr_segment_plan: n=%lld out of range", (long long)n);
+    DR_REQUIRE(rows >= 0 && rows < (1ll << 31) - 1, "dr_segment_plan: rows=%lld out of range", (long long)rows);
+    DR_REQUIRE(id_bits == 32 || id_bits == 64, "dr_segment_plan: id_bits must be 32 or 64");
+    DR_REQUIRE(plan != nullptr && ((uintptr_t)plan % 256 == 0), "dr_segment_plan: plan must be 256-byte aligned");
+    DR_REQUIRE(ids != nullptr || n == 0, "dr_segment_plan: ids is NULL");
+    PlanLayout L;
+    if (plan_layout(n, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_segment_plan: workspace %lld < required %lld", (long long)plan_bytes,
+                (long long)L.total);
+    char* base = (char*)plan;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* hdr = (int32_t*)(base + L.hdr);
+    uint32_t* keys_in = (uint32_t*)(base + L.keys_in);
+    uint32_t* keys_out = (uint32_t*)(base + L.keys_out);
+    int32_t* vals_in = (int32_t*)(base + L.vals_in);
+    int32_t* vals_out = (int32_t*)(base + L.vals_out);
+    int32_t* flags = (int32_t*)(base + L.flags);
+    int32_t* segidx = (int32_t*)(base + L.segidx);
+    int32_t* uniq = (int32_t*)(base + L.uniq);
+    int32_t* seg_start = (int32_t*)(base + L.seg_start);
+    if (n == 0) {
+        hipLaunchKernelGGL(plan_empty_kernel, dim3(1), dim3(1), 0, st, hdr, seg_start);
+        DR_CHECK_LAUNCH("dr_segment_plan(empty)");
+        return DR_OK;
+    }
+    int grid = grid_for(n, 256);
+    if (id_bits == 32)
+        hipLaunchKernelGGL((plan_keys_kernel<int32_t>), dim3(grid), dim3(256), 0, st, (const int32_t*)ids, n, rows,
+                           keys_in, vals_in);
+    else
+        hipLaunchKernelGGL((plan_keys_kernel<int64_t>), dim3(grid), dim3(256), 0, st, (const int64_t*)ids, n, rows,
+                           keys_in, vals_in);
+    DR_CHECK_LAUNCH("plan_keys_kernel");
+    unsigned end_bit = 1;
+    while (end_bit < 32 && ((uint64_t)rows >> end_bit) != 0) ++end_bit;  // enough bits for the sentinel `rows`
+    size_t tb = (size_t)L.temp_bytes;
+    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, keys_in, keys_out, vals_in,
+                                                               vals_out, (size_t)n, 0u, end_bit, st, false)));
+    hipLaunchKernelGGL(plan_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, flags);
+    DR_CHECK_LAUNCH("plan_heads_kernel");
+    tb = (size_t)L.temp_bytes;
+    DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, segidx, (int32_t)0, (size_t)n,
+                                                             rocprim::plus<int32_t>(), st, false)));
+    hipLaunchKernelGGL(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start,
+                       hdr);
+    DR_CHECK_LAUNCH("plan_finalize_kernel");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_segment_plan_view(void* plan, int64_t n, const int32_t** sorted_pos, const int32_t** uniq_ids,
+                                        const int32_t** seg_start, const int32_t** num_segments) {
+    DR_REQUIRE(plan != nullptr && n >= 0, "dr_segment_plan_view: bad arguments");
+    PlanLayout L;
+    if (plan_layout(n, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    char* base = (char*)plan;
+    if (sorted_pos) *sorted_pos = (const int32_t*)(base + L.vals_out);
+    if (uniq_ids) *uniq_ids = (const int32_t*)(base + L.uniq);
+    if (seg_start) *seg_start = (const int32_t*)(base + L.seg_start);
+    if (num_segments) *num_segments = (const int32_t*)(base + L.hdr);
+    return DR_OK;
+}
+
+namespace dr {
+// shared by scatter-add, sparse update and the fused steps
+int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
+               const int32_t* src_idx, const float* coef, int64_t n, void* plan, int kind, const dr_opt_params* opt,
+               hipStream_t st) {
+    PlanLayout L;
+    if (plan_layout(n, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    char* base = (char*)plan;
+    SegArgs a;
+    a.table = table;
+    a.slot0 = slot0;
+    a.slot1 = slot1;
+    a.rows = rows;
+    a.k = k;
+    a.src = src;
+    a.src_rows = src_rows;
+    a.src_idx = src_idx;
+    a.coef = coef;
+    a.sorted_pos = (const int32_t*)(base + L.vals_out);
+    a.uniq = (const int32_t*)(base + L.uniq);
+    a.seg_start = (const int32_t*)(base + L.seg_start);
+    a.nseg = (const int32_t*)(base + L.hdr);
+    a.kind = kind;
+    if (opt) a.opt = make_optp(opt);
+    else memset(&a.opt, 0, sizeof(a.opt));
+    if (dispatch_seg(a, n, st) != 0) DR_FAIL(DR_ERR_ARG, "segment kernel: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("seg_update_kernel");
+    return DR_OK;
+}
+
+int check_opt(const dr_opt_params* opt, const float* slot0, const float* slot1, const char* who) {
+    DR_REQUIRE(opt != nullptr, "%s: opt is NULL", who);
+    DR_REQUIRE(opt->kind >= DR_OPT_SGD && opt->kind <= DR_OPT_RMSPROP, "%s: bad optimizer kind %d", who, opt->kind);
+    DR_REQUIRE(opt->reg_mode >= DR_REG_TOUCHED && opt->reg_mode <= DR_REG_NONE, "%s: bad reg_mode %d", who,
+               opt->reg_mode);
+    if (opt->kind != DR_OPT_SGD) DR_REQUIRE(slot0 != nullptr, "%s: optimizer kind %d needs slot0", who, opt->kind);
+    if (opt->kind == DR_OPT_ADAM || opt->kind == DR_OPT_RMSPROP)
+        DR_REQUIRE(slot1 != nullptr, "%s: optimizer kind %d needs slot1", who, opt->kind);
+    return DR_OK;
+}
+}  // namespace dr
+
+extern "C" int32_t dr_scatter_add_sorted_f32(float* gtable, int64_t rows, int32_t k, const float* src,
+                                             int64_t src_rows, const int32_t* src_idx, const float* coef, int64_t n,
+                                             void* plan, void* stream) {
+    DR_REQUIRE(rows >= 0 && k >= 1 && n >= 0 && src_rows >= 0, "dr_scatter_add_sorted_f32: bad sizes");
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(gtable && src && plan, "dr_scatter_add_sorted_f32: NULL pointer");
+    return seg_launch(gtable, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, KIND_ACC, nullptr,
+                      (hipStream_t)stream);
+}
+
+extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* slot1, int64_t rows, int32_t k,
+                                            const float* src, int64_t src_rows, const int32_t* src_idx,
+                                            const float* coef, int64_t n, void* plan, const dr_opt_params* opt,
+                                            void* stream) {
+    DR_REQUIRE(rows >= 0 && k >= 1 && n >= 0 && src_rows >= 0, "dr_sparse_row_update_f32: bad sizes");
+    int rc = check_opt(opt, slot0, slot1, "dr_sparse_row_update_f32");
+    if (rc != DR_OK) return rc;
+    DR_REQUIRE(opt->reg_mode != DR_REG_DENSE,
+               "dr_sparse_row_update_f32: DR_REG_DENSE is served by dr_scatter_add_sorted_f32 + dr_dense_update_f32");
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(table && src && plan, "dr_sparse_row_update_f32: NULL pointer");
+    return seg_launch(table, slot0, slot1, rows, k, src, src_rows, src_idx, coef, n, plan, opt->kind, opt,
+                      (hipStream_t)stream);
+}
+
+extern "C" int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, const float* grad, int64_t count,
+                                       const dr_opt_params* opt, void* stream) {
+    DR_REQUIRE(count >= 0, "dr_dense_update_f32: negative count");
+    int rc = check_opt(opt, slot0, slot1, "dr_dense_update_f32");
+    if (rc != DR_OK) return rc;
+    if (count == 0) return DR_OK;
+    DR_REQUIRE(w != nullptr, "dr_dense_update_f32: w is NULL");
+    OptP o = make_optp(opt);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = grid_for(count, 256, 4);
+    switch (opt->kind) {
+        case DR_OPT_SGD:
+            hipLaunchKernelGGL((dense_update_kernel<DR_OPT_SGD>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad,
+                               count, o);
+            break;
+        case DR_OPT_ADAM:
+            hipLaunchKernelGGL((dense_update_kernel<DR_OPT_ADAM>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad,
+                               count, o);
+            break;
+        case DR_OPT_ADAGRAD:
+            hipLaunchKernelGGL((dense_update_kernel<DR_OPT_ADAGRAD>), dim3(grid), dim3(256), 0, st, w, slot0, slot1,
+                               grad, count, o);
+            break;
+        default:
+            hipLaunchKernelGGL((dense_update_kernel<DR_OPT_RMSPROP>), dim3(grid), dim3(256), 0, st, w, slot0, slot1,
+                               grad, count, o);
+            break;
+    }
+    DR_CHECK_LAUNCH("dr_dense_update_f32");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_rownorm_clip_f32(float* table, int64_t rows, int32_t k, float clip, void* stream) {
+    DR_REQUIRE(rows >= 0 && k >= 1 && clip > 0.0f, "dr_rownorm_clip_f32: bad arguments");
+    if (rows == 0) return DR_OK;
+    DR_REQUIRE(table != nullptr, "dr_rownorm_clip_f32: table is NULL");
+    RowShape s = row_shape(k);
+    hipStream_t st = (hipStream_t)stream;
+    bool ok = false;
+#define DR_C(V_, L_)                                                                                            \
+    if (!ok && s.V == V_ && s.LPR == L_) {                                                                      \
+        hipLaunchKernelGGL((rownorm_clip_kernel<V_, L_>), dim3(grid_for(rows, 1, 256 / L_)), dim3(256), 0, st,  \
+                           table, rows, k, clip);                                                               \
+        ok = true;                                                                                              \
+    }
+    DR_C(4, 1) DR_C(4, 2) DR_C(4, 4) DR_C(4, 8) DR_C(4, 16) DR_C(4, 32) DR_C(4, 64)
+    DR_C(2, 1) DR_C(2, 2) DR_C(2, 4) DR_C(2, 8) DR_C(2, 16) DR_C(2, 32) DR_C(2, 64)
+    DR_C(1, 1) DR_C(1, 2) DR_C(1, 4) DR_C(1, 8) DR_C(1, 16) DR_C(1, 32) DR_C(1, 64)
+#undef DR_C
+    DR_REQUIRE(ok, "dr_rownorm_clip_f32: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("dr_rownorm_clip_f32");
+    return DR_OK;
+}

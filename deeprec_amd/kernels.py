@@ -1,0 +1,429 @@
+"""Torch-tensor front end of the C ABI (device memory and streams only; no torch math here).
+
+Every function takes CUDA(HIP) tensors, validates shapes / dtypes / contiguity on the host
+(the kernels assume them), and enqueues on torch's current stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import OptParams, check
+
+OPT_SGD, OPT_ADAM, OPT_ADAGRAD, OPT_RMSPROP = 0, 1, 2, 3
+REG_TOUCHED, REG_DENSE, REG_NONE = 0, 1, 2
+SCORE_DOT, SCORE_NEG_SQDIST, SCORE_TWO_DIST = 0, 1, 2
+LOSS_BCE, LOSS_SQ = 0, 1
+OOB_ZERO, OOB_ERROR = 0, 1
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/HIP tensor (deeprec_amd has no CPU path)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have %d dims, got shape %s" % (name, ndim, tuple(t.shape)))
+    return t
+
+
+def _ids(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/HIP tensor" % name)
+    if t.dtype not in (torch.int32, torch.int64):
+        raise TypeError("%s must be int32 or int64, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t, (32 if t.dtype == torch.int32 else 64)
+
+
+def _i32(t, name):
+    t = _req(t, torch.int32, name)
+    return t
+
+
+def opt_params(kind, lr=0.0, alpha=0.0, beta1=0.9, beta2=0.999, eps=1e-8, rho=0.9, momentum=0.0, reg=0.0,
+               reg_mode=REG_TOUCHED):
+    return OptParams(kind, lr, alpha, beta1, beta2, eps, rho, momentum, reg, reg_mode)
+
+
+# ------------------------------------------------------------------ K1
+def gather(table, ids, oob="zero"):
+    """tf.nn.embedding_lookup(table, ids) (bprmf.py:37).  table [R,k] or [R]; ids any shape."""
+    table = _req(table, torch.float32, "table")
+    ids, bits = _ids(ids, "ids")
+    vec = table.dim() == 1
+    k = 1 if vec else table.shape[1]
+    if table.dim() not in (1, 2):
+        raise ValueError("table must be [rows] or [rows, k]")
+    n = ids.numel()
+    out = torch.empty(tuple(ids.shape) + (() if vec else (k,)), dtype=torch.float32, device=table.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=table.device)
+    check(_abi.lib().dr_gather_f32(_ptr(table), table.shape[0], k, _ptr(ids), n, bits, _ptr(out),
+                                   OOB_ERROR if oob == "error" else OOB_ZERO, _ptr(cnt), _stream()), "dr_gather_f32")
+    if oob == "error":
+        bad = int(cnt.item())
+        if bad:
+            raise IndexError("gather: %d ids out of range [0,%d)" % (bad, table.shape[0]))
+    return out
+
+
+# ------------------------------------------------------------------ K2
+class SegmentPlan:
+    """Stable sort of an id list + run boundaries, held in a device workspace."""
+
+    def __init__(self, ids, rows, workspace=None):
+        ids, bits = _ids(ids, "ids")
+        self.n = ids.numel()
+        self.rows = int(rows)
+        need = check(_abi.lib().dr_segment_plan_bytes(self.n), "dr_segment_plan_bytes")
+        if workspace is None:
+            workspace = torch.empty(need, dtype=torch.uint8, device=ids.device)
+        if workspace.numel() < need or workspace.data_ptr() % 256:
+            raise ValueError("plan workspace too small / misaligned (%d < %d)" % (workspace.numel(), need))
+        self.ws = workspace
+        check(_abi.lib().dr_segment_plan(_ptr(ids), self.n, bits, self.rows, _ptr(self.ws), self.ws.numel(),
+                                         _stream()), "dr_segment_plan")
+
+    def view(self):
+        """(sorted_pos[n], uniq_ids[nseg], seg_start[nseg+1]) as host-synchronised torch tensors (debug/tests)."""
+        ptrs = [C.c_void_p() for _ in range(4)]
+        check(_abi.lib().dr_segment_plan_view(_ptr(self.ws), self.n, *[C.byref(p) for p in ptrs]),
+              "dr_segment_plan_view")
+        base = self.ws.data_ptr()
+        as_i32 = self.ws.view(torch.int32)
+
+        def sl(p, count):
+            o = (p.value - base) // 4
+            return as_i32[o:o + count]
+
+        nseg = int(sl(ptrs[3], 1).item())
+        return sl(ptrs[0], self.n).clone(), sl(ptrs[1], nseg).clone(), sl(ptrs[2], nseg + 1).clone()
+
+
+def scatter_add(gtable, ids, src, src_idx=None, coef=None, plan=None):
+    """gtable[ids[e]] += coef[e] * src[src_idx[e]] in place, duplicates summed deterministically."""
+    gtable = _req(gtable, torch.float32, "gtable")
+    src = _req(src, torch.float32, "src")
+    k = 1 if gtable.dim() == 1 else gtable.shape[1]
+    n = ids.numel()
+    if src.numel() % k:
+        raise ValueError("src does not hold rows of %d floats" % k)
+    src_rows = src.numel() // k
+    if src_idx is None and src_rows < n:
+        raise ValueError("src holds %d rows < %d ids" % (src_rows, n))
+    if src_idx is not None and _i32(src_idx, "src_idx").numel() != n:
+        raise ValueError("src_idx must have one entry per id")
+    if coef is not None and _req(coef, torch.float32, "coef").numel() != n:
+        raise ValueError("coef must have one entry per id")
+    if plan is None:
+        plan = SegmentPlan(ids, gtable.shape[0])
+    if plan.n != n or plan.rows != gtable.shape[0]:
+        raise ValueError("plan was built for a different id list / table")
+    check(_abi.lib().dr_scatter_add_sorted_f32(_ptr(gtable), gtable.shape[0], k, _ptr(src), src_rows, _ptr(src_idx),
+                                               _ptr(coef), n, _ptr(plan.ws), _stream()), "dr_scatter_add_sorted_f32")
+    return gtable
+
+
+def _slots(opt, slot0, slot1, like, name):
+    if opt.kind != OPT_SGD:
+        if slot0 is None or _req(slot0, torch.float32, name + ".slot0").shape != like.shape:
+            raise ValueError("%s: optimizer kind %d needs slot0 shaped like the table" % (name, opt.kind))
+    if opt.kind in (OPT_ADAM, OPT_RMSPROP):
+        if slot1 is None or _req(slot1, torch.float32, name + ".slot1").shape != like.shape:
+            raise ValueError("%s: optimizer kind %d needs slot1 shaped like the table" % (name, opt.kind))
+
+
+def sparse_row_update(table, slot0, slot1, ids, src, opt, src_idx=None, coef=None, plan=None):
+    table = _req(table, torch.float32, "table")
+    src = _req(src, torch.float32, "src")
+    _slots(opt, slot0, slot1, table, "sparse_row_update")
+    k = 1 if table.dim() == 1 else table.shape[1]
+    n = ids.numel()
+    src_rows = src.numel() // k
+    if src_idx is None and src_rows < n:
+        raise ValueError("src holds %d rows < %d ids" % (src_rows, n))
+    if src_idx is not None:
+        _i32(src_idx, "src_idx")
+    if coef is not None:
+        _req(coef, torch.float32, "coef")
+    if plan is None:
+        plan = SegmentPlan(ids, table.shape[0])
+    check(_abi.lib().dr_sparse_row_update_f32(_ptr(table), _ptr(slot0), _ptr(slot1), table.shape[0], k, _ptr(src),
+                                              src_rows, _ptr(src_idx), _ptr(coef), n, _ptr(plan.ws), C.byref(opt),
+                                              _stream()), "dr_sparse_row_update_f32")
+    return table
+
+
+def dense_update(w, slot0, slot1, grad, opt):
+    w = _req(w, torch.float32, "w")
+    _slots(opt, slot0, slot1, w, "dense_update")
+    if grad is not None and _req(grad, torch.float32, "grad").shape != w.shape:
+        raise ValueError("grad must be shaped like w")
+    check(_abi.lib().dr_dense_update_f32(_ptr(w), _ptr(slot0), _ptr(slot1), _ptr(grad), w.numel(), C.byref(opt),
+                                         _stream()), "dr_dense_update_f32")
+    return w
+
+
+def rownorm_clip(table, clip=1.0):
+    table = _req(table, torch.float32, "table", 2)
+    check(_abi.lib().dr_rownorm_clip_f32(_ptr(table), table.shape[0], table.shape[1], float(clip), _stream()),
+          "dr_rownorm_clip_f32")
+    return table
+
+
+# ------------------------------------------------------------------ fused steps
+class StepWorkspace:
+    """Scratch of the fused training steps, sized once for (B, k, tables, reg_mode)."""
+
+    def __init__(self, B, k, num_user, num_item, reg_mode, device):
+        self.key = (int(B), int(k), int(num_user), int(num_item), int(reg_mode))
+        need = check(_abi.lib().dr_pairwise_step_bytes(B, k, num_user, num_item, reg_mode), "dr_pairwise_step_bytes")
+        self.buf = torch.empty(need, dtype=torch.uint8, device=device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+
+
+def _step_ws(ws, B, k, nu, ni, opt, device):
+    if ws is None:
+        ws = StepWorkspace(B, k, nu, ni, opt.reg_mode, device)
+    if ws.key != (int(B), int(k), int(nu), int(ni), int(opt.reg_mode)):
+        raise ValueError("StepWorkspace was sized for %s" % (ws.key,))
+    return ws
+
+
+def _check_pq(P, Q, u, ids):
+    P = _req(P, torch.float32, "P", 2)
+    Q = _req(Q, torch.float32, "Q", 2)
+    if P.shape[1] != Q.shape[1]:
+        raise ValueError("P and Q must share k")
+    B = u.numel()
+    for name, t in ids:
+        if _i32(t, name).numel() != B:
+            raise ValueError("%s must have %d entries" % (name, B))
+    return B
+
+
+def bpr_step(P, Q, slotsP, slotsQ, u, i, j, opt, ws=None):
+    """One BPRMF.train_op (bprmf.py:114-123) in place; returns the device scalar sum_b -log sigmoid(x_b)."""
+    B = _check_pq(P, Q, u, (("u", u), ("i", i), ("j", j)))
+    _slots(opt, slotsP[0], slotsP[1], P, "bpr_step(P)")
+    _slots(opt, slotsQ[0], slotsQ[1], Q, "bpr_step(Q)")
+    ws = _step_ws(ws, B, P.shape[1], P.shape[0], Q.shape[0], opt, P.device)
+    check(_abi.lib().dr_bpr_step_f32(_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), P.shape[0], _ptr(Q), _ptr(slotsQ[0]),
+                                     _ptr(slotsQ[1]), Q.shape[0], P.shape[1], _ptr(u), _ptr(i), _ptr(j), B,
+                                     C.byref(opt), _ptr(ws.loss), _ptr(ws.buf), ws.buf.numel(), _stream()),
+          "dr_bpr_step_f32")
+    return ws.loss
+
+
+def bpr_forward(P, Q, u, i, j):
+    B = _check_pq(P, Q, u, (("u", u), ("i", i), ("j", j)))
+    g = torch.empty(B, dtype=torch.float32, device=P.device)
+    loss_b = torch.empty_like(g)
+    stash = torch.empty((B, P.shape[1]), dtype=torch.float32, device=P.device)
+    check(_abi.lib().dr_bpr_forward_f32(_ptr(P), _ptr(Q), P.shape[0], Q.shape[0], P.shape[1], _ptr(u), _ptr(i),
+                                        _ptr(j), B, _ptr(g), _ptr(loss_b), _ptr(stash), _stream()),
+          "dr_bpr_forward_f32")
+    return g, loss_b, stash
+
+
+def pointwise_forward(P, Q, u, i, loss_kind, y=None, BU=None, BI=None, mu=0.0, want_grad=False):
+    """GMF / MF forward: returns pred[B] (and g, loss_b, stash when want_grad)."""
+    B = _check_pq(P, Q, u, (("u", u), ("i", i)))
+    if loss_kind == LOSS_SQ:
+        if _req(BU, torch.float32, "BU", 1).shape[0] != P.shape[0] or _req(BI, torch.float32, "BI", 1).shape[0] != Q.shape[0]:
+            raise ValueError("bias vectors must match the tables")
+    pred = torch.empty(B, dtype=torch.float32, device=P.device)
+    g = loss_b = stash = None
+    if want_grad:
+        if y is None or _req(y, torch.float32, "y").numel() != B:
+            raise ValueError("labels y[B] are required for gradients")
+        g = torch.empty_like(pred)
+        loss_b = torch.empty_like(pred)
+        stash = torch.empty((B, P.shape[1]), dtype=torch.float32, device=P.device)
+    check(_abi.lib().dr_pointwise_forward_f32(_ptr(P), _ptr(Q), _ptr(BU), _ptr(BI), float(mu), P.shape[0], Q.shape[0],
+                                              P.shape[1], loss_kind, _ptr(u), _ptr(i), _ptr(y), B, _ptr(g),
+                                              _ptr(loss_b), _ptr(pred), _ptr(stash), _stream()),
+          "dr_pointwise_forward_f32")
+    return (pred, g, loss_b, stash) if want_grad else pred
+
+
+def pointwise_step(P, Q, slotsP, slotsQ, u, i, y, loss_kind, opt, BU=None, BI=None, slotsBU=(None, None),
+                   slotsBI=(None, None), mu=0.0, ws=None):
+    B = _check_pq(P, Q, u, (("u", u), ("i", i)))
+    if _req(y, torch.float32, "y").numel() != B:
+        raise ValueError("y must have %d entries" % B)
+    _slots(opt, slotsP[0], slotsP[1], P, "pointwise_step(P)")
+    _slots(opt, slotsQ[0], slotsQ[1], Q, "pointwise_step(Q)")
+    if loss_kind == LOSS_SQ:
+        if _req(BU, torch.float32, "BU", 1).shape[0] != P.shape[0] or _req(BI, torch.float32, "BI", 1).shape[0] != Q.shape[0]:
+            raise ValueError("bias vectors must match the tables")
+        _slots(opt, slotsBU[0], slotsBU[1], BU, "pointwise_step(BU)")
+        _slots(opt, slotsBI[0], slotsBI[1], BI, "pointwise_step(BI)")
+    ws = _step_ws(ws, B, P.shape[1], P.shape[0], Q.shape[0], opt, P.device)
+    check(_abi.lib().dr_pointwise_step_f32(
+        _ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), P.shape[0], _ptr(Q), _ptr(slotsQ[0]), _ptr(slotsQ[1]), Q.shape[0],
+        P.shape[1], _ptr(BU), _ptr(slotsBU[0]), _ptr(slotsBU[1]), _ptr(BI), _ptr(slotsBI[0]), _ptr(slotsBI[1]),
+        float(mu), loss_kind, _ptr(u), _ptr(i), _ptr(y), B, C.byref(opt), _ptr(ws.loss), _ptr(ws.buf),
+        ws.buf.numel(), _stream()), "dr_pointwise_step_f32")
+    return ws.loss
+
+
+def hinge_step(P, Q, accP, accQ, u, i, j, opt, keep=1.0, margin=0.5, clip=1.0, mask_pos=None, mask_neg=None, ws=None):
+    """One CML step (cml.py:72-81,120) in place."""
+    B = _check_pq(P, Q, u, (("u", u), ("i", i), ("j", j)))
+    _slots(opt, accP, None, P, "hinge_step(P)")
+    _slots(opt, accQ, None, Q, "hinge_step(Q)")
+    for name, m in (("mask_pos", mask_pos), ("mask_neg", mask_neg)):
+        if m is not None and tuple(_req(m, torch.uint8, name).shape) != (B, P.shape[1]):
+            raise ValueError("%s must be uint8 [B,k]" % name)
+    ws = _step_ws(ws, B, P.shape[1], P.shape[0], Q.shape[0], opt, P.device)
+    check(_abi.lib().dr_hinge_step_f32(_ptr(P), _ptr(accP), P.shape[0], _ptr(Q), _ptr(accQ), Q.shape[0], P.shape[1],
+                                       _ptr(u), _ptr(i), _ptr(j), _ptr(mask_pos), _ptr(mask_neg), float(keep),
+                                       float(margin), float(clip if clip is not None else 0.0), B, C.byref(opt),
+                                       _ptr(ws.loss), _ptr(ws.buf), ws.buf.numel(), _stream()), "dr_hinge_step_f32")
+    return ws.loss
+
+
+def pair_dot(A, B_, a_idx, b_idx):
+    """k-ordered fmaf chain A[a_idx[n]] . B[b_idx[n]]  (BPRMF.predict, bprmf.py:168-173)."""
+    A = _req(A, torch.float32, "A", 2)
+    B_ = _req(B_, torch.float32, "B", 2)
+    if A.shape[1] != B_.shape[1]:
+        raise ValueError("A and B must share k")
+    n = a_idx.numel()
+    if _i32(a_idx, "a_idx").numel() != _i32(b_idx, "b_idx").numel():
+        raise ValueError("index lists differ in length")
+    out = torch.empty(n, dtype=torch.float32, device=A.device)
+    check(_abi.lib().dr_pair_dot_f32(_ptr(A), A.shape[0], _ptr(B_), B_.shape[0], A.shape[1], _ptr(a_idx), _ptr(b_idx),
+                                     n, _ptr(out), _stream()), "dr_pair_dot_f32")
+    return out
+
+
+# ------------------------------------------------------------------ NFM
+def bi_interaction_fwd(E, feats):
+    E = _req(E, torch.float32, "E", 2)
+    feats = _req(feats, torch.int32, "feats", 2)
+    B, F = feats.shape
+    fm = torch.empty((B, E.shape[1]), dtype=torch.float32, device=E.device)
+    s = torch.empty_like(fm)
+    check(_abi.lib().dr_bi_interaction_fwd_f32(_ptr(E), E.shape[0], E.shape[1], _ptr(feats), B, F, _ptr(fm), _ptr(s),
+                                               _stream()), "dr_bi_interaction_fwd_f32")
+    return fm, s
+
+
+def bi_interaction_bwd(E, feats, gfm, s):
+    E = _req(E, torch.float32, "E", 2)
+    feats = _req(feats, torch.int32, "feats", 2)
+    B, F = feats.shape
+    if tuple(_req(gfm, torch.float32, "gfm").shape) != (B, E.shape[1]) or tuple(_req(s, torch.float32, "sum").shape) != (B, E.shape[1]):
+        raise ValueError("gfm / sum must be [B,k]")
+    gv = torch.empty((B, F, E.shape[1]), dtype=torch.float32, device=E.device)
+    check(_abi.lib().dr_bi_interaction_bwd_f32(_ptr(E), E.shape[0], E.shape[1], _ptr(feats), B, F, _ptr(gfm), _ptr(s),
+                                               _ptr(gv), _stream()), "dr_bi_interaction_bwd_f32")
+    return gv
+
+
+# ------------------------------------------------------------------ K6
+def _csr(ptr, idx, Nu, name):
+    if ptr is None:
+        return None, None
+    ptr = _i32(ptr, name + "_ptr")
+    idx = _i32(idx, name + "_idx")
+    if ptr.numel() != Nu + 1:
+        raise ValueError("%s_ptr must have Nu+1 entries" % name)
+    return ptr, idx
+
+
+def score_topk(U, I, K, score_kind=SCORE_DOT, U2=None, I2=None, alpha=0.0, item_bias=None, train=None, targets=None):
+    """All-items scoring + masked top-K + rank-of-target (RankingMetrics.py:82-101).
+    train / targets: (ptr[Nu+1], idx[nnz]) int32 CSR (idx ascending per user) or None.
+    Returns (topk_idx[Nu,K] int32, topk_score[Nu,K] f32, tgt_rank[nnz] int32 or None)."""
+    U = _req(U, torch.float32, "U", 2)
+    I = _req(I, torch.float32, "I", 2)
+    Nu, k = U.shape
+    Ni = I.shape[0]
+    if I.shape[1] != k:
+        raise ValueError("U and I must share k")
+    if score_kind == SCORE_TWO_DIST:
+        if tuple(_req(U2, torch.float32, "U2", 2).shape) != (Nu, k) or tuple(_req(I2, torch.float32, "I2", 2).shape) != (Ni, k):
+            raise ValueError("U2 / I2 must match U / I")
+    if item_bias is not None and _req(item_bias, torch.float32, "item_bias", 1).numel() != Ni:
+        raise ValueError("item_bias must be [Ni]")
+    tp, ti = _csr(*(train if train is not None else (None, None)), Nu, "train")
+    gp, gi = _csr(*(targets if targets is not None else (None, None)), Nu, "tgt")
+    dev = U.device
+    topk_idx = torch.empty((Nu, K), dtype=torch.int32, device=dev)
+    topk_score = torch.empty((Nu, K), dtype=torch.float32, device=dev)
+    nt = gi.numel() if gi is not None else 0
+    rank = torch.empty(nt, dtype=torch.int32, device=dev) if gi is not None else None
+    need = check(_abi.lib().dr_score_topk_bytes(Nu, Ni, k, K, nt, score_kind), "dr_score_topk_bytes")
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    check(_abi.lib().dr_score_topk_f32(_ptr(U), _ptr(U2), Nu, _ptr(I), _ptr(I2), _ptr(item_bias), Ni, k, score_kind,
+                                       float(alpha), _ptr(tp), _ptr(ti), _ptr(gp), _ptr(gi), nt, K, _ptr(topk_idx),
+                                       _ptr(topk_score), _ptr(rank), _ptr(ws), ws.numel(), _stream()),
+          "dr_score_topk_f32")
+    return topk_idx, topk_score, rank
+
+
+def topk_rank(scores, K, train=None, targets=None):
+    """Same selection on a given score matrix [Nu,Ni] (NeuMF and other non-bilinear scores)."""
+    scores = _req(scores, torch.float32, "scores", 2)
+    Nu, Ni = scores.shape
+    tp, ti = _csr(*(train if train is not None else (None, None)), Nu, "train")
+    gp, gi = _csr(*(targets if targets is not None else (None, None)), Nu, "tgt")
+    dev = scores.device
+    topk_idx = torch.empty((Nu, K), dtype=torch.int32, device=dev)
+    topk_score = torch.empty((Nu, K), dtype=torch.float32, device=dev)
+    nt = gi.numel() if gi is not None else 0
+    rank = torch.empty(nt, dtype=torch.int32, device=dev) if gi is not None else None
+    ws = torch.empty(2 * ((nt * 4 + 255) // 256 * 256) + 256, dtype=torch.uint8, device=dev)
+    check(_abi.lib().dr_topk_rank_f32(_ptr(scores), Nu, Ni, _ptr(tp), _ptr(ti), _ptr(gp), _ptr(gi), nt, K,
+                                      _ptr(topk_idx), _ptr(topk_score), _ptr(rank), _ptr(ws), ws.numel(), _stream()),
+          "dr_topk_rank_f32")
+    return topk_idx, topk_score, rank
+
+
+def score_matrix(U, I, score_kind=SCORE_DOT, U2=None, I2=None, alpha=0.0, item_bias=None, sigmoid=False):
+    """Dense [Nu,Ni] score matrix through the same MFMA GEMM (GMF.predict over a catalog, small catalogs)."""
+    U = _req(U, torch.float32, "U", 2)
+    I = _req(I, torch.float32, "I", 2)
+    if U.shape[1] != I.shape[1]:
+        raise ValueError("U and I must share k")
+    if score_kind == SCORE_TWO_DIST:
+        if tuple(_req(U2, torch.float32, "U2", 2).shape) != tuple(U.shape) or tuple(_req(I2, torch.float32, "I2", 2).shape) != tuple(I.shape):
+            raise ValueError("U2 / I2 must match U / I")
+    if item_bias is not None and _req(item_bias, torch.float32, "item_bias", 1).numel() != I.shape[0]:
+        raise ValueError("item_bias must be [Ni]")
+    out = torch.empty((U.shape[0], I.shape[0]), dtype=torch.float32, device=U.device)
+    need = check(_abi.lib().dr_score_topk_bytes(U.shape[0], I.shape[0], U.shape[1], 1, 0, score_kind),
+                 "dr_score_topk_bytes")
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=U.device)
+    check(_abi.lib().dr_score_matrix_f32(_ptr(U), _ptr(U2), U.shape[0], _ptr(I), _ptr(I2), _ptr(item_bias), I.shape[0],
+                                         U.shape[1], score_kind, float(alpha), 1 if sigmoid else 0, _ptr(out),
+                                         _ptr(ws), ws.numel(), _stream()), "dr_score_matrix_f32")
+    return out
+
+
+# ------------------------------------------------------------------ helpers
+def init_normal_(w, seed, stddev):
+    w = _req(w, torch.float32, "w")
+    check(_abi.lib().dr_init_normal_f32(_ptr(w), w.numel(), int(seed), float(stddev), _stream()), "dr_init_normal_f32")
+    return w
+
+
+def sum_f32(x):
+    x = _req(x, torch.float32, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(_abi.lib().dr_sum_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "dr_sum_f32")
+    return out

@@ -1,0 +1,241 @@
+/* deeprec_amd.h -- C ABI of the MI355X-native DeepRec embedding/interaction hot path.
+ *
+ * The reference (cheungdaven/DeepRec) has no FFI: its hot path runs inside TensorFlow
+ * ops called from Python model classes.  Each entry point below therefore cites the
+ * reference call site (file:line under /root/reference) whose TensorFlow op(s) it
+ * replaces; INTEGRATION.md shows the ctypes binding a maintainer adds on the Python side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (DR_ERR_*); dr_last_error()
+ *     returns the message of the calling thread's last failure;
+ *   - all pointers except `stream` are DEVICE pointers owned by the caller (torch
+ *     tensors); the library never allocates or frees memory: scratch comes in through
+ *     a workspace whose size the matching *_workspace_bytes() query returns;
+ *   - `stream` is a hipStream_t (NULL = the null stream); all work is enqueued
+ *     asynchronously on it; entry points are re-entrant across streams as long as
+ *     workspaces are not shared;
+ *   - tables and activations are fp32 row-major [rows, k]; ids are int32 (id_bits=32)
+ *     or int64 (id_bits=64);
+ *   - duplicate-row sums use the "blocked position order" defined in DESIGN.md
+ *     (deterministic, bit-repeatable; DR_SEG_CHUNK contributions per block).
+ */
+#ifndef DEEPREC_AMD_H
+#define DEEPREC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_OK 0
+#define DR_ERR_ARG (-1)       /* null pointer, bad size, unsupported k / id_bits ... */
+#define DR_ERR_WORKSPACE (-2) /* workspace too small                                 */
+#define DR_ERR_LAUNCH (-3)    /* HIP reported a launch / runtime failure             */
+
+#define DR_SEG_CHUNK 32
+
+/* out-of-range id policy of dr_gather_f32 ([TF-ext] tf.nn.embedding_lookup raises on
+ * CPU and returns a zero row on GPU; both are explicit here). */
+#define DR_OOB_ZERO 0  /* write a zero row, count it in *oob_count if non-NULL        */
+#define DR_OOB_ERROR 1 /* same device behaviour; callers must check *oob_count != 0   */
+
+/* optimizer kinds */
+#define DR_OPT_SGD 0
+#define DR_OPT_ADAM 1    /* [TF-ext] ApplyAdam kernel; eps 1e-8 (TF1) or 1e-7 (Keras) */
+#define DR_OPT_ADAGRAD 2 /* [TF-ext] ApplyAdagrad; accumulators start at 0.1          */
+#define DR_OPT_RMSPROP 3 /* [TF-ext] ApplyRMSProp (nnmf.py:84)                        */
+
+/* L2 regulariser modes */
+#define DR_REG_TOUCHED 0 /* grad = segsum + reg*w on gathered rows only (deviation)   */
+#define DR_REG_DENSE 1   /* reference semantics: every row gets reg*w (bprmf.py:118-120) */
+#define DR_REG_NONE 2    /* true sparse gradient, no L2 (cml.py:77-79)                */
+
+/* score kinds of dr_score_topk_f32 */
+#define DR_SCORE_DOT 0        /* bprmf.py:91 / Caser eval SeqRecMetrics.py:213        */
+#define DR_SCORE_NEG_SQDIST 1 /* cml.py:151-153                                       */
+#define DR_SCORE_TWO_DIST 2   /* SeqRecMetrics.py:122-123 (AttRec / PRME)             */
+
+/* hyper-parameters of one optimizer application (all fp32) */
+typedef struct dr_opt_params {
+    int32_t kind;    /* DR_OPT_*                                               */
+    float lr;        /* SGD / Adagrad / RMSProp learning rate                  */
+    float alpha;     /* Adam: lr*sqrt(1-beta2^t)/(1-beta1^t), computed by host */
+    float beta1;     /* Adam                                                   */
+    float beta2;     /* Adam                                                   */
+    float eps;       /* Adam / RMSProp epsilon                                 */
+    float rho;       /* RMSProp decay                                          */
+    float momentum;  /* RMSProp momentum                                       */
+    float reg;       /* L2 coefficient (reg_rate)                              */
+    int32_t reg_mode;/* DR_REG_*                                               */
+} dr_opt_params;
+
+const char* dr_last_error(void);
+int32_t dr_version(void);
+
+/* ---- K1: embedding lookup -------------------------------------------------------
+ * Replaces tf.nn.embedding_lookup at bprmf.py:37,84-86, gmf.py:66-67, neumf.py:73-76,
+ * cml.py:68-70, mf.py:50-53, nfm.py:54,74, nnmf.py:51-54, Caser.py:61-64,
+ * AttRec.py:142,145,190-193, PRME.py:62-63.
+ * out[n, :] = table[ids[n], :]  (ids of any rank are passed flattened). */
+int32_t dr_gather_f32(const float* table, int64_t rows, int32_t k, const void* ids, int64_t n,
+                      int32_t id_bits, float* out, int32_t oob_policy, int32_t* oob_count,
+                      void* stream);
+
+/* ---- K2: backward of the lookup -------------------------------------------------
+ * Replaces the implicit IndexedSlices gradient + de-duplicating segment sum behind
+ * tape.gradient (bprmf.py:121) and Optimizer.minimize (gmf.py:77, neumf.py:129,
+ * cml.py:79, mf.py:103, nfm.py:82, nnmf.py:84, Caser.py:85, AttRec.py:110, PRME.py:98).
+ *
+ * A "segment plan" is the stable sort of an id list plus its run boundaries; it lives
+ * in a caller-provided workspace and is consumed by the kernels below. */
+int64_t dr_segment_plan_bytes(int64_t n);
+int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, int64_t rows, void* plan,
+                        int64_t plan_bytes, void* stream);
+/* Device pointers into a built plan (valid until the workspace is reused). */
+int32_t dr_segment_plan_view(void* plan, int64_t n, const int32_t** sorted_pos,
+                             const int32_t** uniq_ids, const int32_t** seg_start,
+                             const int32_t** num_segments);
+
+/* gtable[ids[e], :] += coef[e] * src[src_idx[e], :], duplicates combined in blocked
+ * position order.  src_idx NULL = e; coef NULL = 1.  Contributions whose src_idx is
+ * outside [0, src_rows) and destinations outside [0, rows) are skipped. */
+int32_t dr_scatter_add_sorted_f32(float* gtable, int64_t rows, int32_t k, const float* src,
+                                  int64_t src_rows, const int32_t* src_idx, const float* coef,
+                                  int64_t n, void* plan, void* stream);
+
+/* ---- K5: sparse row update ------------------------------------------------------
+ * Replaces Optimizer.apply_gradients / minimize on embedding tables (same call sites
+ * as K2; hyper-parameters bprmf.py:62, gmf.py:77, cml.py:79, mf.py:103, nfm.py:82).
+ * For every segment s of the plan: g = blocked_sum_e coef[e]*src[src_idx[e]] (+ reg*w
+ * in DR_REG_TOUCHED), then one optimizer application on row uniq_ids[s] of `table`
+ * and its slot tables (Adam: slot0=m, slot1=v; Adagrad: slot0=acc; RMSProp: ms, mom).
+ * DR_REG_DENSE is served by dr_dense_update_f32 over a dense gradient instead. */
+int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* slot1, int64_t rows, int32_t k,
+                                 const float* src, int64_t src_rows, const int32_t* src_idx,
+                                 const float* coef, int64_t n, void* plan, const dr_opt_params* opt,
+                                 void* stream);
+
+/* Whole-tensor optimizer application: g = grad[i] (may be NULL = 0) + reg*w[i].
+ * Serves DR_REG_DENSE tables (bprmf.py:118-122: the l2_loss term makes the table
+ * gradient dense) and the small dense weights of NeuMF/NFM/NNMF/AttRec/Caser. */
+int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, const float* grad, int64_t count,
+                            const dr_opt_params* opt, void* stream);
+
+/* cml.py:80-81  tf.clip_by_norm(table, clip, axes=[1]) applied in place. */
+int32_t dr_rownorm_clip_f32(float* table, int64_t rows, int32_t k, float clip, void* stream);
+
+/* ---- K3/K4/K5 fused: pairwise (BPR) training step -------------------------------
+ * Replaces BPRMF.train_op (bprmf.py:114-123): 3 gathers, 2 dot products, -log(sigmoid)
+ * loss, gradient, de-duplication and optimizer step.
+ * Forward: g[b] = dL/dx_b, loss_b[b], stash[b,:] = g[b]*(Q[i_b]-Q[j_b]).
+ * Then Q rows are updated from (ids=[i;j], coef=[g;-g], src=P[u]) and P rows from the
+ * stash, both through dr_sparse_row_update_f32 semantics (or the dense path).
+ * ws must hold dr_pairwise_step_bytes(...) (the same query serves the pointwise and hinge
+ * steps).  loss_out[0] = sum_b loss_b (fixed-order reduction; the L2 term is NOT included
+ * -- hosts add it if they display it).  Samples with an out-of-range id contribute nothing. */
+int64_t dr_pairwise_step_bytes(int64_t B, int32_t k, int64_t num_user, int64_t num_item,
+                               int32_t reg_mode);
+int32_t dr_bpr_step_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q,
+                        float* Qslot0, float* Qslot1, int64_t num_item, int32_t k,
+                        const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                        const dr_opt_params* opt, float* loss_out, void* ws, int64_t ws_bytes,
+                        void* stream);
+
+/* Forward only: x_ui - x_uj and -log(sigmoid) per sample (bprmf.py:84-92,118-119). */
+int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t num_user, int64_t num_item,
+                           int32_t k, const int32_t* u, const int32_t* i, const int32_t* j,
+                           int64_t B, float* g_out, float* loss_b, float* stash, void* stream);
+
+/* ---- pointwise models: GMF (gmf.py:57-79, loss_kind 0 = BCE on sigmoid(p.q)) and biased MF
+ * (mf.py:37-55,96-103, loss_kind 1 = squared error on p.q + b_u + b_i + mu).
+ * forward: pred[b] (sigmoid / rating), and when labels y are given loss_b[b], g[b] = dL/dlogit,
+ * stash[b,:] = g[b]*Q[i_b].  Any of g_out / loss_b / pred / stash may be NULL (predict path:
+ * gmf.py:160-161, mf.py:117-118).  The step updates BU, BI (k=1 tables), Q, P in that order. */
+int32_t dr_pointwise_forward_f32(const float* P, const float* Q, const float* BU, const float* BI,
+                                 float mu, int64_t num_user, int64_t num_item, int32_t k,
+                                 int32_t loss_kind, const int32_t* u, const int32_t* i, const float* y,
+                                 int64_t B, float* g_out, float* loss_b, float* pred, float* stash,
+                                 void* stream);
+int32_t dr_pointwise_step_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q,
+                              float* Qslot0, float* Qslot1, int64_t num_item, int32_t k, float* BU,
+                              float* BUslot0, float* BUslot1, float* BI, float* BIslot0,
+                              float* BIslot1, float mu, int32_t loss_kind, const int32_t* u,
+                              const int32_t* i, const float* y, int64_t B, const dr_opt_params* opt,
+                              float* loss_out, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- CML step (cml.py:72-81,120): d = sum(dropout((p-q)^2)), hinge max(d_pos-d_neg+margin,0),
+ * sparse Adagrad on the gathered rows (opt->reg_mode must be DR_REG_NONE), then
+ * clip_by_norm(rows, clip) over both tables (clip <= 0 skips it: CMLwarp-style callers).
+ * mask_pos / mask_neg are [B,k] 0/1 dropout keep masks (NULL = keep all); kept elements are
+ * scaled by 1/keep ([TF-ext] tf.nn.dropout). */
+int32_t dr_hinge_step_f32(float* P, float* Pacc, int64_t num_user, float* Q, float* Qacc,
+                          int64_t num_item, int32_t k, const int32_t* u, const int32_t* i,
+                          const int32_t* j, const uint8_t* mask_pos, const uint8_t* mask_neg,
+                          float keep, float margin, float clip, int64_t B, const dr_opt_params* opt,
+                          float* loss_out, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- predict: per-pair scores ---------------------------------------------------
+ * Replaces BPRMF.predict (bprmf.py:168-173) and the dot inside GMF/MF predict.
+ * out[n] = k-ordered fp32 fmaf chain of A[a_idx[n],:] . B[b_idx[n],:]  (the same chain
+ * the MFMA scoring kernel produces, so predict() and score_topk agree bit for bit). */
+int32_t dr_pair_dot_f32(const float* A, int64_t rowsA, const float* B, int64_t rowsB, int32_t k,
+                        const int32_t* a_idx, const int32_t* b_idx, int64_t n, float* out,
+                        void* stream);
+
+/* ---- NFM bi-interaction (nfm.py:54-61) ------------------------------------------
+ * fm[b,:] = 0.5*((sum_f v)^2 - sum_f v^2), v = E[feats[b,f],:]; sum_out[b,:] = sum_f v.
+ * bwd: gv[b,f,:] = gfm[b,:] * (sum[b,:] - v[b,f,:])  (row gradients for K2). */
+int32_t dr_bi_interaction_fwd_f32(const float* E, int64_t rows, int32_t k, const int32_t* feats,
+                                  int64_t B, int32_t F, float* fm, float* sum_out, void* stream);
+int32_t dr_bi_interaction_bwd_f32(const float* E, int64_t rows, int32_t k, const int32_t* feats,
+                                  int64_t B, int32_t F, const float* gfm, const float* sum_in,
+                                  float* gv, void* stream);
+
+/* ---- K6: full-catalog scoring + masked top-K + rank-of-target -------------------
+ * Replaces the per-user predict + Python sort of RankingMetrics.evaluate
+ * (RankingMetrics.py:82-101) and the numpy all-pairs scoring of SeqRecMetrics
+ * (SeqRecMetrics.py:122-123, 213).  Scores are an fp32 MFMA GEMM (k-ordered fmaf chain)
+ * and never leave the chip.
+ *   U[Nu,k], I[Ni,k] (+ U2/I2 and alpha for DR_SCORE_TWO_DIST, item_bias[Ni] optional)
+ *   train CSR (train_ptr[Nu+1], train_idx sorted ascending per user): masked items
+ *   targets CSR (tgt_ptr[Nu+1], tgt_idx): held-out items whose rank is wanted
+ * Outputs: topk_idx/topk_score [Nu,K] ordered by (score desc, item id asc) with -1 / -inf
+ * padding; tgt_rank[nnz targets] = number of unmasked items ranked before the target
+ * (or -1 if the target is masked). */
+int64_t dr_score_topk_bytes(int64_t Nu, int64_t Ni, int32_t k, int32_t K, int64_t n_targets,
+                            int32_t score_kind);
+int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu, const float* I,
+                          const float* I2, const float* item_bias, int64_t Ni, int32_t k,
+                          int32_t score_kind, float alpha, const int32_t* train_ptr,
+                          const int32_t* train_idx, const int32_t* tgt_ptr, const int32_t* tgt_idx,
+                          int64_t n_targets, int32_t K, int32_t* topk_idx, float* topk_score,
+                          int32_t* tgt_rank, void* ws, int64_t ws_bytes, void* stream);
+
+/* Same selection on a caller-provided score matrix scores[Nu, Ni] (NeuMF / any model
+ * whose score is not a bilinear form; RankingMetrics.py:91-101).  ws: 2 * round_up(4 *
+ * n_targets, 256) bytes when n_targets > 0. */
+int32_t dr_topk_rank_f32(const float* scores, int64_t Nu, int64_t Ni, const int32_t* train_ptr,
+                         const int32_t* train_idx, const int32_t* tgt_ptr, const int32_t* tgt_idx,
+                         int64_t n_targets, int32_t K, int32_t* topk_idx, float* topk_score,
+                         int32_t* tgt_rank, void* ws, int64_t ws_bytes, void* stream);
+
+/* Dense score matrix out[Nu, Ni] through the same MFMA GEMM (GMF.predict over a catalog,
+ * gmf.py:160-161 with act = 1 (sigmoid); SeqRecMetrics.py:122-123, 213 with act = 0).
+ * Distance kinds need a workspace of dr_score_topk_bytes(Nu, Ni, k, 1, 0, kind). */
+int32_t dr_score_matrix_f32(const float* U, const float* U2, int64_t Nu, const float* I,
+                            const float* I2, const float* item_bias, int64_t Ni, int32_t k,
+                            int32_t score_kind, float alpha, int32_t act, float* out, void* ws,
+                            int64_t ws_bytes, void* stream);
+
+/* ---- helpers --------------------------------------------------------------------
+ * Counter-based N(0, stddev^2) init: w[r,c] = stddev * normal(hash(seed, r*k+c)); the
+ * same function is restated in oracle/ so 5 GB tables never travel. */
+int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, float stddev, void* stream);
+/* Fixed-order sum of x[0..n) into out[0] (deterministic loss reduction). */
+int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPREC_AMD_H */

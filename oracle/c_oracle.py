@@ -1,0 +1,76 @@
+"""ctypes front end of oracle/liboracle.so (TEST INFRASTRUCTURE ONLY, see oracle/__init__.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            build()
+        _lib = C.CDLL(_PATH)
+        _lib.or_counter_normal.restype = C.c_float
+        _lib.or_counter_normal.argtypes = [C.c_uint64, C.c_uint64]
+        _lib.or_bpr_step.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32) if a is not None else None
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def init_normal(count, seed, stddev):
+    w = np.empty(count, np.float32)
+    lib().or_init_normal(_p(w), C.c_int64(count), C.c_uint64(seed), C.c_float(stddev))
+    return w
+
+
+def pair_dot(A, B, ai, bi):
+    A, B, ai, bi = _f32(A), _f32(B), _i32(ai), _i32(bi)
+    out = np.empty(len(ai), np.float32)
+    lib().or_pair_dot(_p(A), _p(B), C.c_int(A.shape[1]), _p(ai), _p(bi), C.c_int64(len(ai)), _p(out))
+    return out
+
+
+def score_matrix(U, I, kind=0, U2=None, I2=None, alpha=0.0, bias=None):
+    U, I, U2, I2, bias = _f32(U), _f32(I), _f32(U2), _f32(I2), _f32(bias)
+    out = np.empty((U.shape[0], I.shape[0]), np.float32)
+    lib().or_score_matrix(_p(U), _p(U2), C.c_int64(U.shape[0]), _p(I), _p(I2), _p(bias), C.c_int64(I.shape[0]),
+                          C.c_int(U.shape[1]), C.c_int(kind), C.c_float(alpha), _p(out))
+    return out
+
+
+def gather(table, ids):
+    table, ids = _f32(table), _i32(ids)
+    out = np.empty((len(ids), table.shape[1]), np.float32)
+    lib().or_gather(_p(table), C.c_int64(table.shape[0]), C.c_int(table.shape[1]), _p(ids), C.c_int64(len(ids)), _p(out))
+    return out
+
+
+def bpr_step(P, Q, slotsP, slotsQ, u, i, j, adam, lr=0.0, alpha=0.0, beta1=0.9, beta2=0.999, eps=1e-8, reg=0.0):
+    """In place on the given fp32 arrays; returns the loss sum."""
+    u, i, j = _i32(u), _i32(i), _i32(j)
+    Pm, Pv = (slotsP + [None, None])[:2] if adam else (None, None)
+    Qm, Qv = (slotsQ + [None, None])[:2] if adam else (None, None)
+    return lib().or_bpr_step(_p(P), _p(Pm), _p(Pv), _p(Q), _p(Qm), _p(Qv), C.c_int(P.shape[1]), _p(u), _p(i), _p(j),
+                             C.c_int64(len(u)), C.c_int(1 if adam else 0), C.c_float(lr), C.c_float(alpha),
+                             C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(reg))

@@ -1,0 +1,53 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/deeprec_amd.h declares, with the ctypes signatures in deeprec_amd/_abi.py covering them all."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "deeprec_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound():
+    from deeprec_amd import _abi
+    lib = _abi.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libdeeprec_amd.so does not export %s" % n
+        assert n in _abi.SIGNATURES, "no ctypes signature for %s" % n
+    assert sorted(_abi.SIGNATURES) == names
+    assert lib.dr_version() >= 100
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from deeprec_amd import _abi
+    with pytest.raises(ImportError):
+        _abi.load(str(tmp_path / "nope.so"))
+
+
+def test_cpu_tensors_rejected():
+    import torch
+    from deeprec_amd import kernels
+    with pytest.raises(TypeError):
+        kernels.gather(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int32))
+
+
+def test_argument_errors_without_gpu():
+    """Argument validation happens before any HIP call, so it is checkable on CPU."""
+    import ctypes as C
+    from deeprec_amd import _abi
+    lib = _abi.lib()
+    rc = lib.dr_gather_f32(None, 10, 0, None, 5, 32, None, 0, None, None)   # k = 0
+    assert rc == -1 and b"bad sizes" in lib.dr_last_error()
+    rc = lib.dr_gather_f32(None, 10, 4, None, 5, 16, None, 0, None, None)   # id_bits = 16
+    assert rc == -1 and b"id_bits" in lib.dr_last_error()
+    assert lib.dr_gather_f32(None, 10, 4, None, 0, 32, None, 0, None, None) == 0   # empty id list is a no-op
+    opt = _abi.OptParams(kind=7)
+    assert lib.dr_dense_update_f32(None, None, None, None, 4, C.byref(opt), None) == -1

@@ -1,0 +1,516 @@
+"""GPU parity tests: every HIP entry point, called through the C ABI (deeprec_amd.kernels ->
+ctypes -> libdeeprec_amd.so), against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): gathered rows, scatter-add sums and top-K indices bit-exact;
+losses / scores / updated rows within 1e-5 relative (fp32).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+
+KS = [1, 10, 30, 64, 100, 128, 150]
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def zipf_ids(rng, n, rows, a=1.05):
+    r = rng.zipf(a, size=n * 2)
+    r = r[r <= rows][:n]
+    while len(r) < n:
+        r = np.concatenate((r, rng.integers(1, rows + 1, n - len(r))))
+    return (r - 1).astype(np.int32)
+
+
+# ------------------------------------------------------------------ K1
+@pytest.mark.parametrize("k", KS)
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_gather_bit_exact(dev, k, idt):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(k)
+    R, n = 1000, 4097
+    table = rng.standard_normal((R, k)).astype(np.float32)
+    ids = rng.integers(0, R, n).astype(idt)
+    ids[:7] = [0, R - 1, 5, 5, 5, -1, R]          # duplicates and out-of-range ids
+    out = N(K.gather(T(table, dev), T(ids, dev)))
+    assert np.array_equal(out.view(np.uint32), ro.gather(table, ids).view(np.uint32))
+    with pytest.raises(IndexError):
+        K.gather(T(table, dev), T(ids, dev), oob="error")
+
+
+def test_gather_shapes_and_empty(dev):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((50, 128)).astype(np.float32)
+    ids2 = rng.integers(0, 50, (128, 10)).astype(np.int32)      # NFM-style [B,F] (nfm.py:54)
+    out = N(K.gather(T(table, dev), T(ids2, dev)))
+    assert out.shape == (128, 10, 128) and np.array_equal(out, table[ids2])
+    assert K.gather(T(table, dev), torch.zeros(0, dtype=torch.int32, device=dev)).shape == (0, 128)
+    vec = rng.standard_normal(50).astype(np.float32)            # bias vectors (mf.py:52-53)
+    idv = rng.integers(0, 50, 77).astype(np.int32)
+    assert np.array_equal(N(K.gather(T(vec, dev), T(idv, dev))), vec[idv])
+
+
+def test_gather_large_c4_shape_properties(dev):
+    """C4-shaped (k=128, 64k-row batch, Zipf ids): checked through a size-independent property
+    (row checksums) plus a sampled exact comparison."""
+    from deeprec_amd import kernels as K
+    R, k, n = 1_000_000, 128, 3 * 65536
+    tab = torch.empty((R, k), dtype=torch.float32, device=dev)
+    K.init_normal_(tab, 7, 0.01)
+    rng = np.random.default_rng(1)
+    ids = zipf_ids(rng, n, R)
+    out = K.gather(tab, T(ids, dev))
+    rowsum = tab.sum(1)
+    assert torch.equal(out.sum(1), rowsum[T(ids, dev).long()])
+    samp = rng.integers(0, n, 64)
+    for e in samp:
+        r = int(ids[e])
+        ref = co.init_normal(k * (r + 1), 7, 0.01)[k * r:]
+        assert np.array_equal(N(out[e]), ref)
+
+
+def test_init_normal_matches_oracle(dev):
+    from deeprec_amd import kernels as K
+    w = torch.empty(100_003, dtype=torch.float32, device=dev)
+    K.init_normal_(w, 1234, 0.01)
+    assert np.array_equal(N(w), co.init_normal(100_003, 1234, 0.01))
+
+
+# ------------------------------------------------------------------ K2
+@pytest.mark.parametrize("n,rows", [(0, 10), (1, 1), (5000, 37), (20000, 100000)])
+def test_segment_plan(dev, n, rows):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, rows, n).astype(np.int32)
+    plan = K.SegmentPlan(T(ids, dev), rows)
+    pos, uniq, seg = plan.view()
+    order, u_ref, seg_ref = ro.segment_plan(ids)
+    assert np.array_equal(N(pos), order)
+    assert np.array_equal(N(uniq), u_ref) and np.array_equal(N(seg), seg_ref)
+
+
+@pytest.mark.parametrize("k", KS)
+def test_scatter_add_bit_exact_and_repeatable(dev, k):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(100 + k)
+    R, n = 300, 6000
+    ids = zipf_ids(rng, n, R, 1.3)                      # heavy duplication: segments > DR_SEG_CHUNK
+    ids[:3] = [R, -4, R + 9]                            # out-of-range destinations are skipped
+    gout = rng.standard_normal((n, k)).astype(np.float32)
+    g0 = rng.standard_normal((R, k)).astype(np.float32)
+    valid = (ids >= 0) & (ids < R)
+    ref = ro.scatter_add(g0, ids[valid], gout[valid])
+    outs = []
+    for _ in range(2):
+        g = T(g0, dev)
+        K.scatter_add(g, T(ids, dev), T(gout, dev))
+        outs.append(N(g))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), "not run-to-run identical"
+    assert np.array_equal(outs[0].view(np.uint32), ref.view(np.uint32))
+
+
+def test_scatter_add_with_src_idx_and_coef(dev):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(5)
+    R, n, k, S = 50, 3000, 30, 400
+    ids = rng.integers(0, R, n).astype(np.int32)
+    src = rng.standard_normal((S, k)).astype(np.float32)
+    sidx = rng.integers(0, S, n).astype(np.int32)
+    coef = rng.standard_normal(n).astype(np.float32)
+    uniq, sums = ro.segment_sums(ids, src, sidx, coef)
+    ref = np.zeros((R, k), np.float32)
+    ref[uniq] = ref[uniq] + sums
+    g = torch.zeros((R, k), dtype=torch.float32, device=dev)
+    K.scatter_add(g, T(ids, dev), T(src, dev), T(sidx, dev), T(coef, dev))
+    assert np.array_equal(N(g).view(np.uint32), ref.view(np.uint32))
+
+
+# ------------------------------------------------------------------ K5
+def _hp(kind, step=3):
+    if kind == ro.OPT_ADAM:
+        return dict(alpha=float(ro.adam_alpha(1e-3, 0.9, 0.999, step)), beta1=0.9, beta2=0.999, eps=1e-7)
+    if kind == ro.OPT_RMSPROP:
+        return dict(lr=1e-3, rho=0.9, momentum=0.0, eps=1e-10)
+    return dict(lr=0.05)
+
+
+def _opt(kind, hp, reg, reg_mode):
+    from deeprec_amd import kernels as K
+    return K.opt_params(kind, lr=hp.get("lr", 0.0), alpha=hp.get("alpha", 0.0), beta1=hp.get("beta1", 0.9),
+                        beta2=hp.get("beta2", 0.999), eps=hp.get("eps", 1e-8), rho=hp.get("rho", 0.9),
+                        momentum=hp.get("momentum", 0.0), reg=reg, reg_mode=reg_mode)
+
+
+def _slots_np(kind, shape, rng):
+    if kind == ro.OPT_SGD:
+        return []
+    if kind == ro.OPT_ADAGRAD:
+        return [np.full(shape, 0.1, np.float32)]
+    return [np.abs(rng.standard_normal(shape)).astype(np.float32) * 1e-3 for _ in range(2)]
+
+
+def close(a, b, rtol=1e-5, atol=1e-7):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("kind", [ro.OPT_SGD, ro.OPT_ADAM, ro.OPT_ADAGRAD, ro.OPT_RMSPROP])
+@pytest.mark.parametrize("k", [1, 30, 128, 150])
+def test_sparse_row_update(dev, kind, k):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(kind * 10 + k)
+    R, n = 200, 3000
+    W = (rng.standard_normal((R, k)) * 0.1).astype(np.float32)
+    slots = _slots_np(kind, (R, k), rng)
+    ids = zipf_ids(rng, n, R, 1.2)
+    src = (rng.standard_normal((n, k)) * 0.1).astype(np.float32)
+    hp = _hp(kind)
+    Wr, sr = ro.sparse_row_update(kind, W, slots, ids, src, None, None, 0.01, ro.REG_TOUCHED, hp)
+    Wd = T(W, dev)
+    sd = [T(s, dev) for s in slots] + [None, None]
+    K.sparse_row_update(Wd, sd[0], sd[1], T(ids, dev), T(src, dev), _opt(kind, hp, 0.01, ro.REG_TOUCHED))
+    close(N(Wd), Wr)
+    for a, b in zip(sd, sr):
+        close(N(a), b)
+    untouched = np.setdiff1d(np.arange(R), ids)
+    assert np.array_equal(N(Wd)[untouched], W[untouched])
+
+
+@pytest.mark.parametrize("kind", [ro.OPT_SGD, ro.OPT_ADAM, ro.OPT_ADAGRAD, ro.OPT_RMSPROP])
+def test_dense_update(dev, kind):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(kind)
+    W = rng.standard_normal(10007).astype(np.float32)
+    G = rng.standard_normal(10007).astype(np.float32)
+    slots = _slots_np(kind, W.shape, rng)
+    hp = _hp(kind)
+    g = (G + np.float32(0.1) * W).astype(np.float32)
+    Wr, sr = ro.opt_apply(kind, W, g, tuple(slots), hp)
+    Wd = T(W, dev)
+    sd = [T(s, dev) for s in slots] + [None, None]
+    K.dense_update(Wd, sd[0], sd[1], T(G, dev), _opt(kind, hp, 0.1, ro.REG_DENSE))
+    close(N(Wd), Wr, atol=1e-6)
+    for a, b in zip(sd, sr):
+        close(N(a), b)
+
+
+def test_rownorm_clip(dev):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(3)
+    W = (rng.standard_normal((777, 100)) * 0.12).astype(np.float32)     # norms around 1.2 and below
+    W[5] = 0
+    Wd = T(W, dev)
+    K.rownorm_clip(Wd, 1.0)
+    close(N(Wd), ro.rownorm_clip(W, 1.0), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ fused steps
+def _bpr_case(rng, nu, ni, k, B, std=0.1):
+    P = (rng.standard_normal((nu, k)) * std).astype(np.float32)
+    Q = (rng.standard_normal((ni, k)) * std).astype(np.float32)
+    u = rng.integers(0, nu, B).astype(np.int32)
+    i = zipf_ids(rng, B, ni, 1.2)
+    j = rng.integers(0, ni, B).astype(np.int32)
+    return P, Q, u, i, j
+
+
+@pytest.mark.parametrize("k", [10, 30, 128, 150])
+def test_bpr_forward(dev, k):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(k)
+    P, Q, u, i, j = _bpr_case(rng, 300, 500, k, 2000, std=0.5)
+    g, lb, stash = K.bpr_forward(T(P, dev), T(Q, dev), T(u, dev), T(i, dev), T(j, dev))
+    lr, gr, _ = ro.bpr_forward(P, Q, u, i, j)
+    close(N(lb), lr, atol=1e-6)
+    close(N(g), gr, atol=1e-6)
+    close(N(stash), gr[:, None] * (Q[i] - Q[j]), atol=1e-6)
+
+
+@pytest.mark.parametrize("kind,reg_mode", [(ro.OPT_ADAM, ro.REG_DENSE), (ro.OPT_ADAM, ro.REG_TOUCHED),
+                                           (ro.OPT_SGD, ro.REG_TOUCHED), (ro.OPT_ADAGRAD, ro.REG_DENSE)])
+@pytest.mark.parametrize("k", [30, 128])
+def test_bpr_step_c1_shape(dev, kind, reg_mode, k):
+    """Config 1 shape (943 x 1682, B=1024; bprmf.py:41,74) - three consecutive steps."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(kind + 7 * reg_mode + k)
+    nu, ni, B = 943, 1682, 1024
+    P, Q, _, _, _ = _bpr_case(rng, nu, ni, k, B, std=0.01)
+    sP, sQ = _slots_np(kind, P.shape, rng), _slots_np(kind, Q.shape, rng)
+    if kind == ro.OPT_ADAM:
+        sP, sQ = [np.zeros_like(P), np.zeros_like(P)], [np.zeros_like(Q), np.zeros_like(Q)]
+    Pd, Qd = T(P, dev), T(Q, dev)
+    sPd = ([T(s, dev) for s in sP] + [None, None])[:2]
+    sQd = ([T(s, dev) for s in sQ] + [None, None])[:2]
+    for step in range(1, 4):
+        _, _, u, i, j = _bpr_case(rng, nu, ni, k, B)
+        hp = _hp(kind, step)
+        P, Q, sP, sQ, loss, _ = ro.pairwise_step(P, Q, sP, sQ, u, i, j, kind, hp, 0.1, reg_mode)
+        l = K.bpr_step(Pd, Qd, sPd, sQd, T(u, dev), T(i, dev), T(j, dev), _opt(kind, hp, 0.1, reg_mode))
+        assert abs(float(l.item()) - loss) <= 1e-5 * abs(loss)
+        close(N(Pd), P, atol=2e-7)
+        close(N(Qd), Q, atol=2e-7)
+        for a, b in list(zip(sPd, sP)) + list(zip(sQd, sQ)):
+            close(N(a), b, atol=1e-9)
+
+
+def test_bpr_step_deterministic_and_oob(dev):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(11)
+    nu, ni, k, B = 500, 400, 128, 4096
+    P, Q, u, i, j = _bpr_case(rng, nu, ni, k, B)
+    u[3], i[9], j[12] = nu, -1, ni + 5                  # samples with an out-of-range id contribute nothing
+    hp = _hp(ro.OPT_ADAM, 1)
+    opt = _opt(ro.OPT_ADAM, hp, 0.01, ro.REG_TOUCHED)
+    res = []
+    for _ in range(2):
+        Pd, Qd = T(P, dev), T(Q, dev)
+        s = [torch.zeros_like(Pd), torch.zeros_like(Pd)], [torch.zeros_like(Qd), torch.zeros_like(Qd)]
+        l = K.bpr_step(Pd, Qd, s[0], s[1], T(u, dev), T(i, dev), T(j, dev), opt)
+        res.append((N(Pd), N(Qd), float(l.item())))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    ok = (u < nu) & (i >= 0) & (j < ni)
+    Pr, Qr, _, _, loss, _ = ro.pairwise_step(P, Q, [np.zeros_like(P)] * 2, [np.zeros_like(Q)] * 2, u[ok], i[ok], j[ok],
+                                             ro.OPT_ADAM, hp, 0.01, ro.REG_TOUCHED)
+    close(res[0][0], Pr, atol=2e-7)
+    close(res[0][1], Qr, atol=2e-7)
+    assert abs(res[0][2] - loss) <= 1e-5 * abs(loss)
+
+
+@pytest.mark.parametrize("loss_kind", ["bce", "sq"])
+def test_pointwise_step(dev, loss_kind):
+    """GMF (gmf.py:57-79: k=10, Adagrad 0.5, N(0,1) init) / MF (mf.py:37-55,96-103: k=30, Adam 1e-3)."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(21)
+    nu, ni, B = 300, 400, 256
+    if loss_kind == "bce":
+        k, kind, reg, std = 10, ro.OPT_ADAGRAD, 0.01, 0.5
+        hp = dict(lr=0.5)
+    else:
+        k, kind, reg, std = 30, ro.OPT_ADAM, 0.01, 0.01
+        hp = dict(alpha=float(ro.adam_alpha(1e-3, 0.9, 0.999, 1)), beta1=0.9, beta2=0.999, eps=1e-8)
+    P = (rng.standard_normal((nu, k)) * std).astype(np.float32)
+    Q = (rng.standard_normal((ni, k)) * std).astype(np.float32)
+    BU = (rng.standard_normal(nu) * 0.01).astype(np.float32)
+    BI = (rng.standard_normal(ni) * 0.01).astype(np.float32)
+    u = rng.integers(0, nu, B).astype(np.int32)
+    i = zipf_ids(rng, B, ni, 1.2)
+    y = (rng.integers(0, 2, B) if loss_kind == "bce" else rng.integers(1, 6, B)).astype(np.float32)
+    mk = (lambda a: [np.full(a.shape, 0.1, np.float32)]) if kind == ro.OPT_ADAGRAD else (lambda a: [np.zeros_like(a), np.zeros_like(a)])
+    for reg_mode in (ro.REG_DENSE, ro.REG_TOUCHED):
+        ref = ro.pointwise_step(P, Q, mk(P), mk(Q), u, i, y, loss_kind, kind, hp, reg, reg_mode, BU, BI, mk(BU), mk(BI), 3.5)
+        Pd, Qd, BUd, BId = T(P, dev), T(Q, dev), T(BU, dev), T(BI, dev)
+        sl = lambda a: [T(s, dev) for s in mk(a)] + [None]
+        sPd, sQd, sBUd, sBId = sl(P), sl(Q), sl(BU), sl(BI)
+        l = K.pointwise_step(Pd, Qd, sPd, sQd, T(u, dev), T(i, dev), T(y, dev), K.LOSS_BCE if loss_kind == "bce" else K.LOSS_SQ,
+                             _opt(kind, hp, reg, reg_mode), BUd if loss_kind == "sq" else None,
+                             BId if loss_kind == "sq" else None, sBUd, sBId, 3.5)
+        assert abs(float(l.item()) - ref[4]) <= 1e-5 * abs(ref[4])
+        close(N(Pd), ref[0], atol=1e-6)
+        close(N(Qd), ref[1], atol=1e-6)
+        if loss_kind == "sq":
+            close(N(BUd), ref[6], atol=1e-6)
+            close(N(BId), ref[7], atol=1e-6)
+    pred = K.pointwise_forward(T(P, dev), T(Q, dev), T(u, dev), T(i, dev), K.LOSS_BCE if loss_kind == "bce" else K.LOSS_SQ,
+                               BU=T(BU, dev), BI=T(BI, dev), mu=3.5)
+    pr = ro.bce_forward(P, Q, u, i, y)[2] if loss_kind == "bce" else ro.sq_forward(P, Q, BU, BI, 3.5, u, i, y)[2]
+    close(N(pred), pr, atol=1e-6)
+
+
+def test_hinge_step_cml(dev):
+    """cml.py:56-81: k=100, margin 0.5, keep 0.98, Adagrad 0.1, clip 1 (dropout masks passed in)."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(31)
+    nu, ni, k, B = 200, 300, 100, 500
+    P = (rng.standard_normal((nu, k)) / np.sqrt(k)).astype(np.float32)
+    Q = (rng.standard_normal((ni, k)) / np.sqrt(k)).astype(np.float32)
+    u = rng.integers(0, nu, B).astype(np.int32)
+    i = zipf_ids(rng, B, ni, 1.2)
+    j = rng.integers(0, ni, B).astype(np.int32)
+    mp = (rng.random((B, k)) < 0.98).astype(np.uint8)
+    mn = (rng.random((B, k)) < 0.98).astype(np.uint8)
+    aP, aQ = np.full_like(P, 0.1), np.full_like(Q, 0.1)
+    Pr, Qr, aPr, aQr, loss, _ = ro.hinge_step(P, Q, aP, aQ, u, i, j, mp, mn, 0.98, 0.5, 0.1, 1.0)
+    Pd, Qd, aPd, aQd = T(P, dev), T(Q, dev), T(aP, dev), T(aQ, dev)
+    l = K.hinge_step(Pd, Qd, aPd, aQd, T(u, dev), T(i, dev), T(j, dev), _opt(ro.OPT_ADAGRAD, dict(lr=0.1), 0.0, ro.REG_NONE),
+                     keep=0.98, margin=0.5, clip=1.0, mask_pos=T(mp, dev), mask_neg=T(mn, dev))
+    assert abs(float(l.item()) - loss) <= 1e-5 * abs(loss)
+    close(N(Pd), Pr, atol=1e-6)
+    close(N(Qd), Qr, atol=1e-6)
+    close(N(aPd), aPr, atol=1e-6)
+    close(N(aQd), aQr, atol=1e-6)
+
+
+def test_bi_interaction(dev):
+    """nfm.py:54-61 at the C3 shape (M=5382, F=10, k=128, B=128)."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(41)
+    M, F, k, B = 5382, 10, 128, 128
+    E = (rng.standard_normal((M, k)) * 0.01).astype(np.float32)
+    feats = rng.integers(0, M, (B, F)).astype(np.int32)
+    fm, s = K.bi_interaction_fwd(T(E, dev), T(feats, dev))
+    fr, sr = ro.bi_interaction_fwd(E, feats)
+    assert np.array_equal(N(s), sr) and np.array_equal(N(fm), fr)      # sequential-in-f sums: bit-exact
+    gfm = rng.standard_normal((B, k)).astype(np.float32)
+    gv = K.bi_interaction_bwd(T(E, dev), T(feats, dev), T(gfm, dev), s)
+    assert np.array_equal(N(gv), ro.bi_interaction_bwd(E, feats, gfm))
+
+
+# ------------------------------------------------------------------ K6
+def _csr(lists):
+    ptr = np.zeros(len(lists) + 1, np.int32)
+    ptr[1:] = np.cumsum([len(l) for l in lists])
+    idx = np.concatenate([np.asarray(l, np.int32) for l in lists]) if ptr[-1] else np.zeros(0, np.int32)
+    return ptr, idx.astype(np.int32)
+
+
+def _eval_case(rng, Nu, Ni, k, ntrain, ntgt, std=0.3):
+    U = (rng.standard_normal((Nu, k)) * std).astype(np.float32)
+    I = (rng.standard_normal((Ni, k)) * std).astype(np.float32)
+    I[Ni // 3] = I[Ni // 5]                               # forced exact score ties -> id tie-break
+    I[Ni // 2] = I[Ni // 5]
+    train, tgt = [], []
+    for u in range(Nu):
+        p = rng.permutation(Ni)
+        train.append(np.sort(p[:rng.integers(0, ntrain + 1)]))
+        t = p[ntrain:ntrain + rng.integers(0, ntgt + 1)]
+        if u % 7 == 0 and len(train[-1]):
+            t = np.concatenate((t, train[-1][:1]))        # a target that is masked -> rank -1
+        tgt.append(t)
+    return U, I, train, tgt
+
+
+def _check_selection(scores, train, tgt, K_, idx, val, rank):
+    off = 0
+    for u in range(scores.shape[0]):
+        top, tops, ranks = ro.topk_and_ranks(scores[u], train[u], tgt[u], K_)
+        n = len(top)
+        assert np.array_equal(idx[u, :n], top), "user %d top-K differs" % u
+        assert np.array_equal(val[u, :n].view(np.uint32), tops.view(np.uint32))
+        assert (idx[u, n:] == -1).all()
+        if rank is not None:
+            assert np.array_equal(rank[off:off + len(tgt[u])], ranks), "user %d ranks differ" % u
+            off += len(tgt[u])
+
+
+@pytest.mark.parametrize("Nu,Ni,k,K_", [(942, 1682, 30, 10), (130, 3706, 64, 10), (65, 700, 150, 50), (3, 17, 1, 5),
+                                        (257, 129, 129, 10)])
+def test_score_topk_dot_exact(dev, Nu, Ni, k, K_):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(Nu + Ni)
+    U, I, train, tgt = _eval_case(rng, Nu, Ni, k, min(40, Ni // 3), 4)
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    idx, val, rank = K.score_topk(T(U, dev), T(I, dev), K_, train=(T(tp, dev), T(ti, dev)), targets=(T(gp, dev), T(gi, dev)))
+    scores = co.score_matrix(U, I, 0)
+    sm = N(K.score_matrix(T(U, dev), T(I, dev)))
+    assert np.array_equal(sm.view(np.uint32), scores.view(np.uint32)), "MFMA scores != k-ordered fmaf chain"
+    _check_selection(scores, train, tgt, K_, N(idx), N(val), N(rank))
+    # BPRMF.predict path gives the same bits (bprmf.py:168-173)
+    a = rng.integers(0, Nu, 500).astype(np.int32)
+    b = rng.integers(0, Ni, 500).astype(np.int32)
+    pd = N(K.pair_dot(T(U, dev), T(I, dev), T(a, dev), T(b, dev)))
+    assert np.array_equal(pd.view(np.uint32), scores[a, b].view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", [1, 2])
+def test_score_topk_distances(dev, kind):
+    """CML (cml.py:151-153) and AttRec/PRME (SeqRecMetrics.py:122-123, alpha=0.2) scores."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(kind)
+    Nu, Ni, k, K_ = 200, 1683, 100 if kind == 1 else 150, 50
+    U, I, train, tgt = _eval_case(rng, Nu, Ni, k, 30, 3, std=0.1)
+    U2 = (rng.standard_normal((Nu, k)) * 0.1).astype(np.float32)
+    I2 = (rng.standard_normal((Ni, k)) * 0.1).astype(np.float32)
+    I2[Ni // 3] = I2[Ni // 5]
+    I2[Ni // 2] = I2[Ni // 5]
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    kw = dict(U2=T(U2, dev), I2=T(I2, dev), alpha=0.2) if kind == 2 else {}
+    idx, val, rank = K.score_topk(T(U, dev), T(I, dev), K_, score_kind=kind, train=(T(tp, dev), T(ti, dev)),
+                                  targets=(T(gp, dev), T(gi, dev)), **kw)
+    scores = co.score_matrix(U, I, kind, U2 if kind == 2 else None, I2 if kind == 2 else None, 0.2)
+    _check_selection(scores, train, tgt, K_, N(idx), N(val), N(rank))
+    sm = N(K.score_matrix(T(U, dev), T(I, dev), score_kind=kind, **kw))
+    assert np.array_equal(sm.view(np.uint32), scores.view(np.uint32))
+    # and the canonical score is within 1e-5 relative of the reference's direct formula
+    if kind == 1:
+        direct = -((U[:, None, :].astype(np.float64) - I[None]) ** 2).sum(2)
+    else:
+        direct = -0.2 * ((U[:, None, :].astype(np.float64) - I[None]) ** 2).sum(2) \
+                 - 0.8 * ((U2[:, None, :].astype(np.float64) - I2[None]) ** 2).sum(2)
+    np.testing.assert_allclose(scores, direct, rtol=1e-5, atol=1e-6)
+
+
+def test_score_topk_caser_bias(dev):
+    """SeqRecMetrics.py:213: user_factors @ item_factors.T + bias_item."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(9)
+    U, I, train, tgt = _eval_case(rng, 100, 900, 300, 20, 2)
+    bias = rng.standard_normal(900).astype(np.float32)
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    idx, val, rank = K.score_topk(T(U, dev), T(I, dev), 50, item_bias=T(bias, dev), train=(T(tp, dev), T(ti, dev)),
+                                  targets=(T(gp, dev), T(gi, dev)))
+    scores = co.score_matrix(U, I, 0, bias=bias)
+    _check_selection(scores, train, tgt, 50, N(idx), N(val), N(rank))
+
+
+def test_topk_rank_on_matrix_saturated_ties(dev):
+    """NeuMF/GMF-style saturating sigmoid scores (neumf.py:115): many exact ties at 1.0 / 0.0."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(17)
+    Nu, Ni = 77, 3706
+    z = rng.standard_normal((Nu, Ni)).astype(np.float32) * 30
+    scores = (1 / (1 + np.exp(-z))).astype(np.float32)
+    assert (scores == 1.0).sum() > 1000
+    _, _, train, tgt = _eval_case(rng, Nu, Ni, 2, 60, 5)
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    idx, val, rank = K.topk_rank(T(scores, dev), 10, train=(T(tp, dev), T(ti, dev)), targets=(T(gp, dev), T(gi, dev)))
+    _check_selection(scores, train, tgt, 10, N(idx), N(val), N(rank))
+    # no mask / no targets
+    idx2, val2, r2 = K.topk_rank(T(scores, dev), 5)
+    _check_selection(scores, [[]] * Nu, [[]] * Nu, 5, N(idx2), N(val2), None)
+
+
+def test_score_topk_large_property(dev):
+    """Larger catalog (no oracle matrix): top-K must be sorted by the total order, unmasked, and
+    consistent with ranks: rank(target) < K  <=>  target in top-K."""
+    from deeprec_amd import kernels as K
+    Nu, Ni, k, K_ = 2048, 100_000, 128, 10
+    U = torch.empty((Nu, k), device=dev)
+    I = torch.empty((Ni, k), device=dev)
+    K.init_normal_(U, 1, 0.1)
+    K.init_normal_(I, 2, 0.1)
+    rng = np.random.default_rng(3)
+    train = [np.sort(rng.choice(Ni, 100, replace=False)) for _ in range(Nu)]
+    tgt = [rng.choice(Ni, 2, replace=False) for _ in range(Nu)]
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    idx, val, rank = K.score_topk(U, I, K_, train=(T(tp, dev), T(ti, dev)), targets=(T(gp, dev), T(gi, dev)))
+    idx, val, rank = N(idx), N(val), N(rank)
+    assert (np.diff(val, axis=1) <= 0).all()
+    Un, In = N(U), N(I)
+    for u in rng.integers(0, Nu, 24):
+        s = co.score_matrix(Un[u:u + 1], In, 0)[0]
+        top, tops, ranks = ro.topk_and_ranks(s, train[u], tgt[u], K_)
+        assert np.array_equal(idx[u], top) and np.array_equal(rank[2 * u:2 * u + 2], ranks)
+    for u in range(Nu):
+        assert not np.isin(idx[u], train[u]).any()
+        for x, t in enumerate(tgt[u]):
+            r = rank[2 * u + x]
+            if r >= 0:
+                assert (r < K_) == (t in idx[u])
