@@ -223,16 +223,20 @@ def bpr_forward(P, Q, u, i, j):
     return loss_b, g, x
 
 
-def pairwise_step(P, Q, slotsP, slotsQ, u, i, j, opt_kind, hp, reg, reg_mode):
+def pairwise_step(P, Q, slotsP, slotsQ, u, i, j, opt_kind, hp, reg, reg_mode, g=None):
     """One BPR-MF training step (bprmf.py:114-123).  Returns
-    (P', Q', slotsP', slotsQ', loss_sum_without_reg, loss_b)."""
+    (P', Q', slotsP', slotsQ', loss_sum_without_reg, loss_b).
+    g: optional per-sample dL/dx to use instead of the oracle's own forward (tests feed the
+    device's g -- itself checked against bpr_forward -- to verify everything downstream of the
+    transcendental functions bit for bit)."""
     P = np.asarray(P, f32)
     Q = np.asarray(Q, f32)
     u = np.asarray(u).reshape(-1)
     i = np.asarray(i).reshape(-1)
     j = np.asarray(j).reshape(-1)
     B = len(u)
-    loss_b, g, _ = bpr_forward(P, Q, u, i, j)
+    loss_b, g_own, _ = bpr_forward(P, Q, u, i, j)
+    g = g_own if g is None else np.asarray(g, f32)
     D = (g[:, None] * (gather(Q, i) - gather(Q, j))).astype(f32)      # dL/dp_u per sample
     Pn, sPn = sparse_row_update(opt_kind, P, slotsP, u, D, np.arange(B), None, reg, reg_mode, hp)
     idsQ = np.concatenate((i, j))

@@ -239,11 +239,22 @@ def test_bpr_forward(dev, k):
     close(N(stash), gr[:, None] * (Q[i] - Q[j]), atol=1e-6)
 
 
+def loose_rows(a, b, lr):
+    """End-to-end bar for rows updated by a normalising optimizer: 1e-5 relative, except that an
+    element whose gradient nearly cancels may move by a small fraction of the step size."""
+    bad = ~np.isclose(a, b, rtol=1e-5, atol=2e-7)
+    assert bad.mean() < 1e-3, "too many elements outside 1e-5: %g" % bad.mean()
+    assert np.abs(a - b).max() <= 0.02 * lr, np.abs(a - b).max()
+
+
 @pytest.mark.parametrize("kind,reg_mode", [(ro.OPT_ADAM, ro.REG_DENSE), (ro.OPT_ADAM, ro.REG_TOUCHED),
                                            (ro.OPT_SGD, ro.REG_TOUCHED), (ro.OPT_ADAGRAD, ro.REG_DENSE)])
 @pytest.mark.parametrize("k", [30, 128])
 def test_bpr_step_c1_shape(dev, kind, reg_mode, k):
-    """Config 1 shape (943 x 1682, B=1024; bprmf.py:41,74) - three consecutive steps."""
+    """Config 1 shape (943 x 1682, B=1024; bprmf.py:41,74) - three consecutive steps.
+    (a) end to end against the oracle's own forward (tolerance); (b) with the device's per-sample
+    dL/dx fed to the oracle, everything after the transcendentals -- stash, duplicate sums, L2,
+    optimizer -- must agree bit for bit."""
     from deeprec_amd import kernels as K
     rng = np.random.default_rng(kind + 7 * reg_mode + k)
     nu, ni, B = 943, 1682, 1024
@@ -254,16 +265,22 @@ def test_bpr_step_c1_shape(dev, kind, reg_mode, k):
     Pd, Qd = T(P, dev), T(Q, dev)
     sPd = ([T(s, dev) for s in sP] + [None, None])[:2]
     sQd = ([T(s, dev) for s in sQ] + [None, None])[:2]
+    Pe, Qe, sPe, sQe = P, Q, sP, sQ                      # "exact" track, driven by the device's g
     for step in range(1, 4):
         _, _, u, i, j = _bpr_case(rng, nu, ni, k, B)
         hp = _hp(kind, step)
+        ud, idd, jd = T(u, dev), T(i, dev), T(j, dev)
+        g_dev = N(K.bpr_forward(Pd, Qd, ud, idd, jd)[0])
         P, Q, sP, sQ, loss, _ = ro.pairwise_step(P, Q, sP, sQ, u, i, j, kind, hp, 0.1, reg_mode)
-        l = K.bpr_step(Pd, Qd, sPd, sQd, T(u, dev), T(i, dev), T(j, dev), _opt(kind, hp, 0.1, reg_mode))
+        Pe, Qe, sPe, sQe, _, _ = ro.pairwise_step(Pe, Qe, sPe, sQe, u, i, j, kind, hp, 0.1, reg_mode, g=g_dev)
+        l = K.bpr_step(Pd, Qd, sPd, sQd, ud, idd, jd, _opt(kind, hp, 0.1, reg_mode))
         assert abs(float(l.item()) - loss) <= 1e-5 * abs(loss)
-        close(N(Pd), P, atol=2e-7)
-        close(N(Qd), Q, atol=2e-7)
-        for a, b in list(zip(sPd, sP)) + list(zip(sQd, sQ)):
-            close(N(a), b, atol=1e-9)
+        assert np.array_equal(N(Pd).view(np.uint32), Pe.view(np.uint32))
+        assert np.array_equal(N(Qd).view(np.uint32), Qe.view(np.uint32))
+        for a, b in list(zip(sPd, sPe)) + list(zip(sQd, sQe)):
+            assert np.array_equal(N(a).view(np.uint32), b.view(np.uint32))
+        loose_rows(N(Pd), P, hp.get("lr", 1e-3))
+        loose_rows(N(Qd), Q, hp.get("lr", 1e-3))
 
 
 def test_bpr_step_deterministic_and_oob(dev):
@@ -282,10 +299,13 @@ def test_bpr_step_deterministic_and_oob(dev):
         res.append((N(Pd), N(Qd), float(l.item())))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
     ok = (u < nu) & (i >= 0) & (j < ni)
+    g_dev = N(K.bpr_forward(T(P, dev), T(Q, dev), T(u, dev), T(i, dev), T(j, dev))[0])
+    assert (g_dev[~ok] == 0).all()
     Pr, Qr, _, _, loss, _ = ro.pairwise_step(P, Q, [np.zeros_like(P)] * 2, [np.zeros_like(Q)] * 2, u[ok], i[ok], j[ok],
-                                             ro.OPT_ADAM, hp, 0.01, ro.REG_TOUCHED)
-    close(res[0][0], Pr, atol=2e-7)
-    close(res[0][1], Qr, atol=2e-7)
+                                             ro.OPT_ADAM, hp, 0.01, ro.REG_TOUCHED, g=g_dev[ok])
+    # dropping the bad samples shifts the 32-blocks of the duplicate sums, so this is a tolerance check
+    loose_rows(res[0][0], Pr, 1e-3)
+    loose_rows(res[0][1], Qr, 1e-3)
     assert abs(res[0][2] - loss) <= 1e-5 * abs(loss)
 
 
