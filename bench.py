@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""bench.py -- headline measurement of the DeepRec embedding/interaction hot path on MI355X.
+
+Workload (BASELINE.json configs[3], SURVEY 8d "C4"): synthetic BPR-MF, 10M users x 1M items, d=128,
+B=65536 (u, i, j) triples per GPU and step, users ~ Uniform, positive items ~ Zipf(1.05), negatives
+~ Uniform; Adam with touched-rows L2 (the reference's optimizer, bprmf.py:62).  It fits one
+GPU, so it is also the N=1 workload; at N>1 the tables are row-sharded (deeprec_amd/sharding.py) and
+every rank processes its own B triples (weak scaling).
+
+One "step" = one pass of the hot path over one batch: 3 lookups, 2 dot products, BPR loss,
+gradient, deterministic duplicate sums, Adam row update (dr_bpr_step_f32).  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--users", type=int, default=10_000_000)
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--k", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--opt", default="adam", choices=["adam", "sgd"])
+    ap.add_argument("--eval-users", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel / eval / gather extras")
+    return ap.parse_args()
+
+
+def zipf_items(n, n_items, a, gen, device):
+    """Zipf(a) over [0, n_items) by inverse-CDF on a float64 table (synthetic, seeded)."""
+    w = torch.arange(1, n_items + 1, dtype=torch.float64, device=device).pow_(-a)
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    r = torch.rand(n, dtype=torch.float64, device=device, generator=gen)
+    return torch.searchsorted(cdf, r).clamp_(max=n_items - 1).to(torch.int32)
+
+
+def make_batches(args, rank, device, n_batches=8):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    out = []
+    for _ in range(n_batches):
+        u = torch.randint(0, args.users, (args.batch,), device=device, generator=gen, dtype=torch.int64).to(torch.int32)
+        i = zipf_items(args.batch, args.items, 1.05, gen, device)
+        j = torch.randint(0, args.items, (args.batch,), device=device, generator=gen, dtype=torch.int64).to(torch.int32)
+        out.append((u.contiguous(), i.contiguous(), j.contiguous()))
+    return out
+
+
+def ev_time(fn, iters, stream):
+    """Average milliseconds of fn() measured with HIP events on the stream the kernels run on."""
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(stream)
+    for _ in range(iters):
+        fn()
+    e.record(stream)
+    e.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path for the product kernels")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from deeprec_amd import kernels as K
+    from deeprec_amd import sharding as sh
+
+    k, B = args.k, args.batch
+    adam = args.opt == "adam"
+    n_slots = 2 if adam else 0
+    stream = torch.cuda.current_stream()
+
+    def opt_for(step):
+        b1p, b2p = 0.9 ** step, 0.999 ** step
+        return K.opt_params(K.OPT_ADAM if adam else K.OPT_SGD, lr=0.05, alpha=1e-3 * (1 - b2p) ** 0.5 / (1 - b1p),
+                            beta1=0.9, beta2=0.999, eps=1e-7, reg=0.1, reg_mode=K.REG_TOUCHED)
+
+    batches = make_batches(args, rank, device)
+    if world == 1:
+        P = torch.empty((args.users, k), dtype=torch.float32, device=device)
+        Q = torch.empty((args.items, k), dtype=torch.float32, device=device)
+        K.init_normal_(P, 1, 0.01)
+        K.init_normal_(Q, 2, 0.01)
+        sP = [torch.zeros_like(P) for _ in range(n_slots)] + [None, None]
+        sQ = [torch.zeros_like(Q) for _ in range(n_slots)] + [None, None]
+        ws = K.StepWorkspace(B, k, args.users, args.items, K.REG_TOUCHED, device)
+
+        def step(t):
+            u, i, j = batches[t % len(batches)]
+            return K.bpr_step(P, Q, sP, sQ, u, i, j, opt_for(t + 1), ws)
+    else:
+        Pt = sh.ShardedTable(args.users, k, world, rank, device, n_slots)
+        Qt = sh.ShardedTable(args.items, k, world, rank, device, n_slots)
+        Pt.init_normal_(K, 1, 0.01)
+        Qt.init_normal_(K, 2, 0.01)
+
+        def step(t):
+            u, i, j = batches[t % len(batches)]
+            return sh.sharded_bpr_step(K, Pt, Qt, u, i, j, opt_for(t + 1))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        step(t)
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        loss = step(args.warmup + t)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    last_loss = float(loss.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    result = {
+        "metric": "train samples/s + top-10 eval users/s; embedding gather GB/s vs HBM peak",
+        "value": value, "unit": "train samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C4 synthetic BPR-MF %dM users x %dM items d=%d, B=%d/GPU, %s touched-rows L2, "
+                               "users~U, items~Zipf(1.05)" % (args.users // 10**6, args.items // 10**6, k, B,
+                                                              "Adam" if adam else "SGD"),
+                   "users": args.users, "items": args.items, "k": k, "batch_per_gpu": B,
+                   "optimizer": args.opt, "reg_mode": "touched",
+                   "parallelism": "single" if world == 1 else "row-sharded x%d (all-to-all)" % world},
+        "last_loss_sum": last_loss,
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        result.update(extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step):
+    """Per-kernel rooflines (HIP events on the launch stream), standalone gather GB/s, eval users/s."""
+    k, B = args.k, args.batch
+    adam = args.opt == "adam"
+    u, i, j = batches[0]
+    opt = opt_for(1)
+    rows_rw = 6 if adam else 2            # (w[,m,v]) read + written per updated row
+    out = {}
+    # --- the kernels of one step, timed one by one --------------------------------------
+    g, loss_b, stash = K.bpr_forward(P, Q, u, i, j)
+    t_fwd = ev_time(lambda: K.bpr_forward(P, Q, u, i, j), 20, stream)
+    idsQ = torch.cat((i, j)).contiguous()
+    coefQ = torch.cat((g, -g)).contiguous()
+    srcQ = torch.cat((u, u)).contiguous()
+    planQ = K.SegmentPlan(idsQ, args.items)
+    planP = K.SegmentPlan(u, args.users)
+    t_planQ = ev_time(lambda: K.SegmentPlan(idsQ, args.items, planQ.ws), 20, stream)
+    t_planP = ev_time(lambda: K.SegmentPlan(u, args.users, planP.ws), 20, stream)
+    nsegQ = int(planQ.view()[1].numel())
+    nsegP = int(planP.view()[1].numel())
+    t_updQ = ev_time(lambda: K.sparse_row_update(Q, sQ[0], sQ[1], idsQ, P, opt, srcQ, coefQ, planQ), 20, stream)
+    t_updP = ev_time(lambda: K.sparse_row_update(P, sP[0], sP[1], u, stash, opt, None, None, planP), 20, stream)
+    row = 4 * k
+    bytes_fwd = B * (12 + 3 * row + row + 8)                          # 3 ids, 3 rows read; stash row, g, loss written
+    bytes_updQ = 2 * B * (12 + row) + nsegQ * (rows_rw * row + 8)      # pos,src_idx,coef + src row per contribution
+    bytes_updP = B * (4 + row) + nsegP * (rows_rw * row + 8)
+    kern = {
+        "bpr_forward_kernel": (t_fwd, bytes_fwd),
+        "seg_update_kernel[Q]": (t_updQ, bytes_updQ),
+        "seg_update_kernel[P]": (t_updP, bytes_updP),
+    }
+    name, (t_dom, b_dom) = max(kern.items(), key=lambda kv: kv[1][0])
+    ach = b_dom / (t_dom * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_ms": t_dom,
+                       "algorithmic_bytes_per_launch": b_dom}
+    out["kernels"] = {n: {"avg_ms": t, "algorithmic_GBps": b / (t * 1e-3) / 1e9, "frac_hbm_peak": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                      for n, (t, b) in kern.items()}
+    out["kernels"]["segment_plan[Q,2B]"] = {"avg_ms": t_planQ}
+    out["kernels"]["segment_plan[P,B]"] = {"avg_ms": t_planP}
+    step_bytes = B * (12 + 3 * rows_rw * row)                          # 9228 B / 3084 B per sample at k=128
+    out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_sample": step_bytes // B,
+                            "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    # --- K1 standalone: 3B lookups (u from P, i and j from Q) ---------------------------------
+    t_gu = ev_time(lambda: K.gather(P, u), 20, stream)
+    t_gi = ev_time(lambda: K.gather(Q, idsQ), 20, stream)
+    gb = lambda n, t: n * (4 + 2 * row) / (t * 1e-3) / 1e9             # n*(4 + 2*4k) bytes
+    out["gather"] = {"users_uniform_10M": {"rows": B, "avg_ms": t_gu, "GBps": gb(B, t_gu), "frac_hbm_peak": gb(B, t_gu) / HBM_PEAK_GBPS},
+                     "items_zipf+uniform_1M": {"rows": 2 * B, "avg_ms": t_gi, "GBps": gb(2 * B, t_gi), "frac_hbm_peak": gb(2 * B, t_gi) / HBM_PEAK_GBPS}}
+    big = torch.randint(0, args.users, (1 << 22,), device=device, dtype=torch.int64).to(torch.int32)
+    t_big = ev_time(lambda: K.gather(P, big), 5, stream)
+    out["gather"]["users_uniform_10M_4Mrows"] = {"rows": 1 << 22, "avg_ms": t_big, "GBps": gb(1 << 22, t_big),
+                                                 "frac_hbm_peak": gb(1 << 22, t_big) / HBM_PEAK_GBPS}
+    del big
+    # --- K6: top-10 eval over the full catalog, 100 masked train items / user, 1 held-out -----
+    Nu = args.eval_users
+    gen = torch.Generator(device=device)
+    gen.manual_seed(7)
+    users = torch.randint(0, args.users, (Nu,), device=device, generator=gen)
+    Uemb = K.gather(P, users.to(torch.int32))
+    tr = torch.sort(torch.randint(0, args.items, (Nu, 100), device=device, generator=gen), 1)[0].to(torch.int32)
+    tp = (torch.arange(Nu + 1, device=device) * 100).to(torch.int32)
+    tg = torch.randint(0, args.items, (Nu,), device=device, generator=gen).to(torch.int32)
+    gp = torch.arange(Nu + 1, device=device).to(torch.int32)
+    ev = lambda: K.score_topk(Uemb, Q, 10, train=(tp, tr.reshape(-1).contiguous()), targets=(gp, tg))
+    t_ev = ev_time(ev, 3, stream)
+    flops = 2.0 * Nu * args.items * k
+    out["eval"] = {"users": Nu, "items": args.items, "K": 10, "avg_ms": t_ev, "users_per_s": Nu / (t_ev * 1e-3),
+                   "TFLOPs": flops / (t_ev * 1e-3) / 1e12, "frac_mfma_f32_peak": flops / (t_ev * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    return out
+
+
+def cpu_baseline(args):
+    """The CPU port of the same step (oracle/c/oracle.c:or_bpr_step, scalar C, 1 thread) on a bounded sample."""
+    from oracle import c_oracle as co
+    k, B = args.k, args.batch
+    Uc = min(args.users, 1_000_000)            # user table scaled down so the sample initialises in seconds
+    Ic = min(args.items, 1_000_000)
+    rng = np.random.default_rng(0)
+    P = co.init_normal(Uc * k, 1, 0.01).reshape(Uc, k)
+    Q = co.init_normal(Ic * k, 2, 0.01).reshape(Ic, k)
+    adam = args.opt == "adam"
+    sP = [np.zeros_like(P), np.zeros_like(P)] if adam else []
+    sQ = [np.zeros_like(Q), np.zeros_like(Q)] if adam else []
+    w = np.arange(1, Ic + 1, dtype=np.float64) ** -1.05
+    cdf = np.cumsum(w) / w.sum()
+    steps, t_total = 0, 0.0
+    while steps < 3 or (t_total < 10.0 and steps < 200):
+        u = rng.integers(0, Uc, B).astype(np.int32)
+        i = np.minimum(np.searchsorted(cdf, rng.random(B)), Ic - 1).astype(np.int32)
+        j = rng.integers(0, Ic, B).astype(np.int32)
+        t0 = time.perf_counter()
+        co.bpr_step(P, Q, sP, sQ, u, i, j, adam, lr=0.05, alpha=1e-3, eps=1e-7, reg=0.1)
+        t_total += time.perf_counter() - t0
+        steps += 1
+    return {"value": steps * B / t_total, "unit": "train samples/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of B=%d on %dM users x %dM items d=%d (user table scaled to %d rows), %s touched-rows L2, "
+                      "scalar C port oracle/c/oracle.c:or_bpr_step" % (steps, B, args.users // 10**6, args.items // 10**6, k, Uc, args.opt),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,7 @@ SIGNATURES = {
     "dr_last_error": (C.c_char_p, []),
     "dr_version": (_i32, []),
     "dr_gather_f32": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _p, _i32, _p, _p]),
+    "dr_scale_rows_f32": (_i32, [_p, _i64, _i32, _p, _p, _i64, _p, _p]),
     "dr_segment_plan_bytes": (_i64, [_i64]),
     "dr_segment_plan": (_i32, [_p, _i64, _i32, _i64, _p, _i64, _p]),
     "dr_segment_plan_view": (_i32, [_p, _i64, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
@@ -53,7 +54,7 @@ SIGNATURES = {
                                  _p, _p, _p, _p, _i64, _p]),
     "dr_topk_rank_f32": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "dr_score_matrix_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _i32, _p, _p, _i64, _p]),
-    "dr_init_normal_f32": (_i32, [_p, _i64, C.c_uint64, _f, _p]),
+    "dr_init_normal_f32": (_i32, [_p, _i64, C.c_uint64, _f, C.c_uint64, _p]),
     "dr_sum_f32": (_i32, [_p, _i64, _p, _p]),
 }
 

@@ -19,9 +19,9 @@ __host__ __device__ inline float counter_normal(uint64_t seed, uint64_t idx) {
 }
 
 __global__ __launch_bounds__(256) void init_normal_kernel(float* __restrict__ w, int64_t count, uint64_t seed,
-                                                          float stddev) {
+                                                          float stddev, uint64_t offset) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-        w[i] = stddev * counter_normal(seed, (uint64_t)i);
+        w[i] = stddev * counter_normal(seed, offset + (uint64_t)i);
 }
 
 // One block, fixed order: thread t sums x[t], x[t+1024], ... sequentially, then a fixed LDS tree.
@@ -42,12 +42,13 @@ __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, 
 extern "C" const char* dr_last_error(void) { return dr::last_error_buf(); }
 extern "C" int32_t dr_version(void) { return 100; }
 
-extern "C" int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, float stddev, void* stream) {
+extern "C" int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, float stddev, uint64_t offset,
+                                      void* stream) {
     DR_REQUIRE(count >= 0, "dr_init_normal_f32: negative count");
     if (count == 0) return DR_OK;
     DR_REQUIRE(w != nullptr, "dr_init_normal_f32: w is NULL");
     hipLaunchKernelGGL(dr::init_normal_kernel, dim3(dr::grid_for(count, 256, 4)), dim3(256), 0, (hipStream_t)stream,
-                       w, count, seed, stddev);
+                       w, count, seed, stddev, offset);
     DR_CHECK_LAUNCH("dr_init_normal_f32");
     return DR_OK;
 }

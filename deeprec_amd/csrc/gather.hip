@@ -94,7 +94,58 @@ static int dispatch_gather(const float* table, int64_t rows, int k, const IdT* i
     return -1;
 }
 
+// out[e,:] = coef[e] * src[idx[e],:]   (idx NULL = e).  Materialises per-contribution gradient rows
+// (g_b * p_u) for the row-sharded path, where they travel to the owning rank before being summed.
+template <int V, int LPR>
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ src, int64_t src_rows, int k,
+                                                         const int32_t* __restrict__ idx,
+                                                         const float* __restrict__ coef, int64_t n,
+                                                         float* __restrict__ out) {
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+    const int cpr = k / V;
+    for (int64_t e = (int64_t)blockIdx.x * RPB + sub; e < n; e += (int64_t)gridDim.x * RPB) {
+        const int64_t r = idx ? (int64_t)idx[e] : e;
+        const float cf = coef[e];
+        const bool ok = r >= 0 && r < src_rows;
+        for (int c = lane; c < cpr; c += LPR) {
+            float v[V];
+            if (ok) {
+                vload<V>(v, src + r * k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) v[x] = cf * v[x];
+            } else {
+#pragma unroll
+                for (int x = 0; x < V; ++x) v[x] = 0.0f;
+            }
+            vstore<V>(out + e * k + c * V, v);
+        }
+    }
+}
+
 }  // namespace dr
+
+extern "C" int32_t dr_scale_rows_f32(const float* src, int64_t src_rows, int32_t k, const int32_t* idx,
+                                     const float* coef, int64_t n, float* out, void* stream) {
+    DR_REQUIRE(src_rows >= 0 && k >= 1 && n >= 0, "dr_scale_rows_f32: bad sizes");
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(src && coef && out, "dr_scale_rows_f32: NULL pointer");
+    dr::RowShape s = dr::row_shape(k);
+    bool ok = false;
+#define DR_F(V_, L_)                                                                                           \
+    if (!ok && s.V == V_ && s.LPR == L_) {                                                                     \
+        hipLaunchKernelGGL((dr::scale_rows_kernel<V_, L_>), dim3(dr::grid_for(n, 1, 256 / L_)), dim3(256), 0,  \
+                           (hipStream_t)stream, src, src_rows, k, idx, coef, n, out);                          \
+        ok = true;                                                                                             \
+    }
+    DR_F(4, 1) DR_F(4, 2) DR_F(4, 4) DR_F(4, 8) DR_F(4, 16) DR_F(4, 32) DR_F(4, 64)
+    DR_F(2, 1) DR_F(2, 2) DR_F(2, 4) DR_F(2, 8) DR_F(2, 16) DR_F(2, 32) DR_F(2, 64)
+    DR_F(1, 1) DR_F(1, 2) DR_F(1, 4) DR_F(1, 8) DR_F(1, 16) DR_F(1, 32) DR_F(1, 64)
+#undef DR_F
+    DR_REQUIRE(ok, "dr_scale_rows_f32: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("dr_scale_rows_f32");
+    return DR_OK;
+}
 
 extern "C" int32_t dr_gather_f32(const float* table, int64_t rows, int32_t k, const void* ids, int64_t n,
                                  int32_t id_bits, float* out, int32_t oob_policy, int32_t* oob_count,

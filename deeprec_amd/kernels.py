@@ -78,6 +78,21 @@ def gather(table, ids, oob="zero"):
     return out
 
 
+def scale_rows(src, coef, idx=None):
+    """out[e] = coef[e] * src[idx[e]] (idx None = e)."""
+    src = _req(src, torch.float32, "src", 2)
+    coef = _req(coef, torch.float32, "coef", 1)
+    n = coef.numel()
+    if idx is not None and _i32(idx, "idx").numel() != n:
+        raise ValueError("idx must have one entry per coef")
+    if idx is None and src.shape[0] < n:
+        raise ValueError("src has fewer rows than coef entries")
+    out = torch.empty((n, src.shape[1]), dtype=torch.float32, device=src.device)
+    check(_abi.lib().dr_scale_rows_f32(_ptr(src), src.shape[0], src.shape[1], _ptr(idx), _ptr(coef), n, _ptr(out),
+                                       _stream()), "dr_scale_rows_f32")
+    return out
+
+
 # ------------------------------------------------------------------ K2
 class SegmentPlan:
     """Stable sort of an id list + run boundaries, held in a device workspace."""
@@ -416,9 +431,10 @@ def score_matrix(U, I, score_kind=SCORE_DOT, U2=None, I2=None, alpha=0.0, item_b
 
 
 # ------------------------------------------------------------------ helpers
-def init_normal_(w, seed, stddev):
+def init_normal_(w, seed, stddev, offset=0):
     w = _req(w, torch.float32, "w")
-    check(_abi.lib().dr_init_normal_f32(_ptr(w), w.numel(), int(seed), float(stddev), _stream()), "dr_init_normal_f32")
+    check(_abi.lib().dr_init_normal_f32(_ptr(w), w.numel(), int(seed), float(stddev), int(offset), _stream()),
+          "dr_init_normal_f32")
     return w
 
 

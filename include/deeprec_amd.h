@@ -82,6 +82,12 @@ int32_t dr_gather_f32(const float* table, int64_t rows, int32_t k, const void* i
                       int32_t id_bits, float* out, int32_t oob_policy, int32_t* oob_count,
                       void* stream);
 
+/* out[e, :] = coef[e] * src[idx[e], :] (idx NULL = e).  No reference counterpart as a separate
+ * op: it materialises the per-sample gradient rows g_b * p_u of bprmf.py:121 for the row-sharded
+ * path (a21), where they are sent to the rank that owns the destination row before being summed. */
+int32_t dr_scale_rows_f32(const float* src, int64_t src_rows, int32_t k, const int32_t* idx,
+                          const float* coef, int64_t n, float* out, void* stream);
+
 /* ---- K2: backward of the lookup -------------------------------------------------
  * Replaces the implicit IndexedSlices gradient + de-duplicating segment sum behind
  * tape.gradient (bprmf.py:121) and Optimizer.minimize (gmf.py:77, neumf.py:129,
@@ -229,9 +235,11 @@ int32_t dr_score_matrix_f32(const float* U, const float* U2, int64_t Nu, const f
                             int64_t ws_bytes, void* stream);
 
 /* ---- helpers --------------------------------------------------------------------
- * Counter-based N(0, stddev^2) init: w[r,c] = stddev * normal(hash(seed, r*k+c)); the
- * same function is restated in oracle/ so 5 GB tables never travel. */
-int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, float stddev, void* stream);
+ * Counter-based ~N(0, stddev^2) init: w[i] = stddev * normal(hash(seed, offset + i)); the
+ * same function is restated in oracle/ so 5 GB tables never travel (stands in for
+ * tf.random.normal at bprmf.py:75-76, whose RNG stream cannot be reproduced). */
+int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, float stddev, uint64_t offset,
+                           void* stream);
 /* Fixed-order sum of x[0..n) into out[0] (deterministic loss reduction). */
 int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream);
 

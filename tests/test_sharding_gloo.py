@@ -1,0 +1,97 @@
+"""world_size-2 (and 3) gloo runs of the row-sharded BPR step on CPU: the exchange logic of
+deeprec_amd/sharding.py must reproduce, bit for bit, the single-process oracle step on the
+concatenated global batch (identical results at every GPU count)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_ops as ro
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case(seed, nu, ni, k, Bg):
+    rng = np.random.default_rng(seed)
+    P = (rng.standard_normal((nu, k)) * 0.1).astype(np.float32)
+    Q = (rng.standard_normal((ni, k)) * 0.1).astype(np.float32)
+    steps = []
+    for _ in range(2):
+        u = rng.integers(0, nu, Bg).astype(np.int32)
+        i = (rng.zipf(1.3, Bg) % ni).astype(np.int32)       # duplicate-heavy
+        j = rng.integers(0, ni, Bg).astype(np.int32)
+        steps.append((u, i, j))
+    return P, Q, steps
+
+
+def _worker(rank, world, port, seed, kind, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import _oracle_ops as ops
+        from deeprec_amd import kernels as K
+        from deeprec_amd import sharding as sh
+        nu, ni, k, Bg = 101, 57, 8, 96
+        P, Q, steps = _case(seed, nu, ni, k, Bg)
+        n_slots = 2 if kind == ro.OPT_ADAM else 0
+        Pt = sh.ShardedTable(nu, k, world, rank, "cpu", n_slots)
+        Qt = sh.ShardedTable(ni, k, world, rank, "cpu", n_slots)
+        Pt.load_global(torch.from_numpy(P))
+        Qt.load_global(torch.from_numpy(Q))
+        Bl = Bg // world
+        losses = []
+        for t, (u, i, j) in enumerate(steps, 1):
+            opt = K.opt_params(kind, lr=0.05, alpha=float(ro.adam_alpha(1e-3, 0.9, 0.999, t)), eps=1e-7, reg=0.01,
+                               reg_mode=K.REG_TOUCHED)
+            sl = slice(rank * Bl, (rank + 1) * Bl)
+            l = sh.sharded_bpr_step(ops, Pt, Qt, torch.from_numpy(u[sl]), torch.from_numpy(i[sl]),
+                                    torch.from_numpy(j[sl]), opt)
+            dist.all_reduce(l)
+            losses.append(float(l))
+        Pfull = sh.all_gather_table(Pt).numpy()
+        Qfull = sh.all_gather_table(Qt).numpy()
+        if rank == 0:
+            np.savez(out, P=Pfull, Q=Qfull, losses=np.array(losses))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind", [ro.OPT_SGD, ro.OPT_ADAM])
+def test_sharded_step_equals_single_process(tmp_path, world, kind):
+    seed = 5
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), seed, kind, out), nprocs=world, join=True)
+    res = np.load(out)
+    P, Q, steps = _case(seed, 101, 57, 8, 96)
+    sP = [np.zeros_like(P), np.zeros_like(P)] if kind == ro.OPT_ADAM else []
+    sQ = [np.zeros_like(Q), np.zeros_like(Q)] if kind == ro.OPT_ADAM else []
+    losses = []
+    for t, (u, i, j) in enumerate(steps, 1):
+        hp = dict(lr=0.05, alpha=float(ro.adam_alpha(1e-3, 0.9, 0.999, t)), beta1=0.9, beta2=0.999, eps=1e-7)
+        P, Q, sP, sQ, loss, _ = ro.pairwise_step(P, Q, sP, sQ, u, i, j, kind, hp, 0.01, ro.REG_TOUCHED)
+        losses.append(loss)
+    assert np.array_equal(res["P"].view(np.uint32), P.view(np.uint32))
+    assert np.array_equal(res["Q"].view(np.uint32), Q.view(np.uint32))
+    np.testing.assert_allclose(res["losses"], losses, rtol=1e-6)
+
+
+def test_shard_helpers():
+    from deeprec_amd import sharding as sh
+    assert [sh.shard_users(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    t = sh.ShardedTable(10, 2, 4, 1, "cpu")
+    assert t.local_rows == 3          # rows 1, 5, 9
+    t3 = sh.ShardedTable(10, 2, 4, 3, "cpu")
+    assert t3.local_rows == 2         # rows 3, 7
