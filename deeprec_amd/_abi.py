@@ -29,11 +29,11 @@ SIGNATURES = {
     "dr_version": (_i32, []),
     "dr_gather_f32": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _p, _i32, _p, _p]),
     "dr_scale_rows_f32": (_i32, [_p, _i64, _i32, _p, _p, _i64, _p, _p]),
-    "dr_segment_plan_bytes": (_i64, [_i64]),
+    "dr_segment_plan_bytes": (_i64, [_i64, _i32]),
     "dr_segment_plan": (_i32, [_p, _i64, _i32, _i64, _p, _i64, _p]),
     "dr_segment_plan_view": (_i32, [_p, _i64, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
-    "dr_scatter_add_sorted_f32": (_i32, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p]),
-    "dr_sparse_row_update_f32": (_i32, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _optp, _p]),
+    "dr_scatter_add_sorted_f32": (_i32, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
+    "dr_sparse_row_update_f32": (_i32, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _optp, _p]),
     "dr_dense_update_f32": (_i32, [_p, _p, _p, _p, _i64, _optp, _p]),
     "dr_rownorm_clip_f32": (_i32, [_p, _i64, _i32, _f, _p]),
     "dr_pairwise_step_bytes": (_i64, [_i64, _i32, _i64, _i64, _i32]),
@@ -64,6 +64,9 @@ def load(path=LIB_PATH):
         raise ImportError(
             "deeprec_amd: %s is missing -- build it with `make -C deeprec_amd/csrc` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback" % path)
+    # torch first: its wheel bundles its own HIP runtime, and a process must end up with ONE runtime.  Loading
+    # this library before torch binds it to /opt/rocm's copy and its launches then see no device.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -47,7 +47,7 @@ extern "C" int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, fl
     DR_REQUIRE(count >= 0, "dr_init_normal_f32: negative count");
     if (count == 0) return DR_OK;
     DR_REQUIRE(w != nullptr, "dr_init_normal_f32: w is NULL");
-    hipLaunchKernelGGL(dr::init_normal_kernel, dim3(dr::grid_for(count, 256, 4)), dim3(256), 0, (hipStream_t)stream,
+    DR_LAUNCH(dr::init_normal_kernel, dim3(dr::grid_for(count, 256, 4)), dim3(256), 0, (hipStream_t)stream,
                        w, count, seed, stddev, offset);
     DR_CHECK_LAUNCH("dr_init_normal_f32");
     return DR_OK;
@@ -55,7 +55,7 @@ extern "C" int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, fl
 
 extern "C" int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream) {
     DR_REQUIRE(n >= 0 && out != nullptr && (x != nullptr || n == 0), "dr_sum_f32: bad arguments");
-    hipLaunchKernelGGL(dr::sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
+    DR_LAUNCH(dr::sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out);
     DR_CHECK_LAUNCH("dr_sum_f32");
     return DR_OK;
 }

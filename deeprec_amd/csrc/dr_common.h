@@ -29,6 +29,14 @@ char* last_error_buf();  // thread-local, defined in abi.hip
         if (e_ != hipSuccess) DR_FAIL(DR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
     } while (0)
 
+// hipGetLastError() is sticky per thread: an unrelated earlier failure (e.g. a probe made while another
+// library initialised HIP) must not be blamed on our launch, so the slate is cleared first.
+#define DR_LAUNCH(...)                   \
+    do {                                 \
+        (void)hipGetLastError();         \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 #define DR_HIP(call)                                                                   \
     do {                                                                               \
         hipError_t e_ = (call);                                                        \

@@ -76,7 +76,7 @@ static int launch_gather(const float* table, int64_t rows, int k, const IdT* ids
     constexpr int U = 4;
     constexpr int RPB = (64 / LPR) * 4;
     int grid = grid_for(n, 1, RPB * U);
-    hipLaunchKernelGGL((gather_kernel<V, LPR, U, IdT>), dim3(grid), dim3(256), 0, st, table, rows, k, ids, n,
+    DR_LAUNCH((gather_kernel<V, LPR, U, IdT>), dim3(grid), dim3(256), 0, st, table, rows, k, ids, n,
                        out, oob_count);
     return 0;
 }
@@ -134,7 +134,7 @@ extern "C" int32_t dr_scale_rows_f32(const float* src, int64_t src_rows, int32_t
     bool ok = false;
 #define DR_F(V_, L_)                                                                                           \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                     \
-        hipLaunchKernelGGL((dr::scale_rows_kernel<V_, L_>), dim3(dr::grid_for(n, 1, 256 / L_)), dim3(256), 0,  \
+        DR_LAUNCH((dr::scale_rows_kernel<V_, L_>), dim3(dr::grid_for(n, 1, 256 / L_)), dim3(256), 0,  \
                            (hipStream_t)stream, src, src_rows, k, idx, coef, n, out);                          \
         ok = true;                                                                                             \
     }

@@ -84,7 +84,7 @@ extern "C" int32_t dr_bi_interaction_fwd_f32(const float* E, int64_t rows, int32
     bool ok = false;
 #define DR_F(V_, L_)                                                                                            \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                      \
-        hipLaunchKernelGGL((bi_fwd_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0,               \
+        DR_LAUNCH((bi_fwd_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0,               \
                            (hipStream_t)stream, E, rows, k, feats, B, F, fm, sum_out);                          \
         ok = true;                                                                                              \
     }
@@ -105,7 +105,7 @@ extern "C" int32_t dr_bi_interaction_bwd_f32(const float* E, int64_t rows, int32
     bool ok = false;
 #define DR_F(V_, L_)                                                                                            \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                      \
-        hipLaunchKernelGGL((bi_bwd_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0,               \
+        DR_LAUNCH((bi_bwd_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0,               \
                            (hipStream_t)stream, E, rows, k, feats, B, F, gfm, sum_in, gv);                      \
         ok = true;                                                                                              \
     }

@@ -10,8 +10,8 @@
 namespace dr {
 
 int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
-               const int32_t* src_idx, const float* coef, int64_t n, void* plan, int kind, const dr_opt_params* opt,
-               hipStream_t st);
+               const int32_t* src_idx, const float* coef, int64_t n, void* plan, int64_t plan_bytes, int kind,
+               const dr_opt_params* opt, hipStream_t st);
 int check_opt(const dr_opt_params* opt, const float* slot0, const float* slot1, const char* who);
 constexpr int KIND_ACC = -1;
 
@@ -310,7 +310,7 @@ struct StepLayout {
 
 using namespace dr;
 
-extern "C" int64_t dr_segment_plan_bytes(int64_t n);
+extern "C" int64_t dr_segment_plan_bytes(int64_t n, int32_t k_max);
 extern "C" int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, int64_t rows, void* plan,
                                    int64_t plan_bytes, void* stream);
 
@@ -318,7 +318,7 @@ namespace dr {
 // stash_rows: B for BPR / pointwise, 2B for hinge.  dense tables only in DR_REG_DENSE.
 static int step_layout(int64_t B, int k, int64_t stash_rows, int64_t nu, int64_t ni, bool dense, StepLayout* L) {
     int64_t BB = B > 0 ? B : 1;
-    int64_t pa = dr_segment_plan_bytes(2 * BB), pb = dr_segment_plan_bytes(2 * BB);
+    int64_t pa = dr_segment_plan_bytes(2 * BB, k), pb = dr_segment_plan_bytes(2 * BB, k);
     if (pa < 0 || pb < 0) return -1;
     int64_t off = 0;
     auto take = [&](int64_t bytes) {
@@ -351,11 +351,11 @@ static int table_update(float* T, float* s0, float* s1, int64_t rows, int k, con
     if (rc != DR_OK) return rc;
     if (opt->reg_mode == DR_REG_DENSE) {
         DR_HIP(hipMemsetAsync(gdense, 0, (size_t)rows * k * 4, st));
-        rc = seg_launch(gdense, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, KIND_ACC, nullptr, st);
+        rc = seg_launch(gdense, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, KIND_ACC, nullptr, st);
         if (rc != DR_OK) return rc;
         return dr_dense_update_f32(T, s0, s1, gdense, rows * (int64_t)k, opt, st);
     }
-    return seg_launch(T, s0, s1, rows, k, src, src_rows, src_idx, coef, n, plan, opt->kind, opt, st);
+    return seg_launch(T, s0, s1, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, opt->kind, opt, st);
 }
 }  // namespace dr
 
@@ -370,7 +370,7 @@ extern "C" int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t nu
     bool ok = false;
 #define DR_F(V_, L_)                                                                                                \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                          \
-        hipLaunchKernelGGL((bpr_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, st, P, Q,    \
+        DR_LAUNCH((bpr_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, st, P, Q,    \
                            num_user, num_item, k, u, i, j, B, g_out, loss_b, stash);                                \
         ok = true;                                                                                                  \
     }
@@ -416,7 +416,7 @@ extern "C" int32_t dr_bpr_step_f32(float* P, float* Pslot0, float* Pslot1, int64
     if (B > 0) {
         rc = dr_bpr_forward_f32(P, Q, num_user, num_item, k, u, i, j, B, g, loss_b, stash, st);
         if (rc != DR_OK) return rc;
-        hipLaunchKernelGGL(bpr_qlists_kernel, dim3(grid_for(B, 256)), dim3(256), 0, st, u, i, j, g, B, idsQ, coefQ, srcQ);
+        DR_LAUNCH(bpr_qlists_kernel, dim3(grid_for(B, 256)), dim3(256), 0, st, u, i, j, g, B, idsQ, coefQ, srcQ);
         DR_CHECK_LAUNCH("bpr_qlists_kernel");
     }
     if (B > 0 || opt->reg_mode == DR_REG_DENSE) {
@@ -448,10 +448,10 @@ extern "C" int32_t dr_pointwise_forward_f32(const float* P, const float* Q, cons
 #define DR_F(V_, L_)                                                                                                 \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                           \
         if (loss_kind == 1)                                                                                          \
-            hipLaunchKernelGGL((pointwise_forward_kernel<V_, L_, true>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, \
+            DR_LAUNCH((pointwise_forward_kernel<V_, L_, true>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, \
                                st, P, Q, BU, BI, mu, num_user, num_item, k, u, i, y, B, g_out, loss_b, pred, stash); \
         else                                                                                                         \
-            hipLaunchKernelGGL((pointwise_forward_kernel<V_, L_, false>), dim3(grid_for(B, 1, 256 / L_)), dim3(256),  \
+            DR_LAUNCH((pointwise_forward_kernel<V_, L_, false>), dim3(grid_for(B, 1, 256 / L_)), dim3(256),  \
                                0, st, P, Q, BU, BI, mu, num_user, num_item, k, u, i, y, B, g_out, loss_b, pred,      \
                                stash);                                                                               \
         ok = true;                                                                                                   \
@@ -551,7 +551,7 @@ extern "C" int32_t dr_hinge_step_f32(float* P, float* Pacc, int64_t num_user, fl
         bool ok = false;
 #define DR_F(V_, L_)                                                                                              \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                        \
-        hipLaunchKernelGGL((hinge_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, st, P, Q, \
+        DR_LAUNCH((hinge_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, st, P, Q, \
                            num_user, num_item, k, u, i, j, mask_pos, mask_neg, keep, margin, B, loss_b, stash);   \
         ok = true;                                                                                                \
     }
@@ -559,7 +559,7 @@ extern "C" int32_t dr_hinge_step_f32(float* P, float* Pacc, int64_t num_user, fl
 #undef DR_F
         DR_REQUIRE(ok, "dr_hinge_step_f32: unsupported k=%d", k);
         DR_CHECK_LAUNCH("hinge_forward_kernel");
-        hipLaunchKernelGGL(hinge_lists_kernel, dim3(grid_for(B, 256)), dim3(256), 0, st, u, i, j, B, idsP, idsQ, coefP);
+        DR_LAUNCH(hinge_lists_kernel, dim3(grid_for(B, 256)), dim3(256), 0, st, u, i, j, B, idsP, idsQ, coefP);
         DR_CHECK_LAUNCH("hinge_lists_kernel");
         // both updates read only the stash, so their order is free
         rc = table_update(Q, Qacc, nullptr, num_item, k, idsQ, 2 * B, stash, 2 * B, nullptr, nullptr, base + L.planA,
@@ -584,7 +584,7 @@ extern "C" int32_t dr_pair_dot_f32(const float* A, int64_t rowsA, const float* B
     DR_REQUIRE(rowsA >= 0 && rowsB >= 0 && k >= 1 && n >= 0, "dr_pair_dot_f32: bad sizes");
     if (n == 0) return DR_OK;
     DR_REQUIRE(A && B && a_idx && b_idx && out, "dr_pair_dot_f32: NULL pointer");
-    hipLaunchKernelGGL(pair_dot_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, A, rowsA, B, rowsB, k,
+    DR_LAUNCH(pair_dot_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, A, rowsA, B, rowsB, k,
                        a_idx, b_idx, n, out);
     DR_CHECK_LAUNCH("dr_pair_dot_f32");
     return DR_OK;

@@ -471,26 +471,26 @@ static int prepare_operands(const float* U, const float* U2, int64_t Nu, const f
     float* iadd = (float*)(base + L.iadd);
     a->cdot = 2.0f;
     if (kind == DR_SCORE_NEG_SQDIST) {
-        if (Nu > 0) hipLaunchKernelGGL(neg_sqnorm_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, U, (const float*)nullptr, Nu, k, 1.0f, 0.0f, uadd);
-        if (Ni > 0) hipLaunchKernelGGL(neg_sqnorm_kernel, dim3(grid_for(Ni, 256)), dim3(256), 0, st, I, (const float*)nullptr, Ni, k, 1.0f, 0.0f, iadd);
+        if (Nu > 0) DR_LAUNCH(neg_sqnorm_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, U, (const float*)nullptr, Nu, k, 1.0f, 0.0f, uadd);
+        if (Ni > 0) DR_LAUNCH(neg_sqnorm_kernel, dim3(grid_for(Ni, 256)), dim3(256), 0, st, I, (const float*)nullptr, Ni, k, 1.0f, 0.0f, iadd);
     } else {
         const float w1 = alpha, w2 = 1.0f - alpha;
         float* ucat = (float*)(base + L.ucat);
         float* icat = (float*)(base + L.icat);
         if (Nu > 0) {
-            hipLaunchKernelGGL(neg_sqnorm_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, U, U2, Nu, k, w1, w2, uadd);
-            hipLaunchKernelGGL(concat_scale_kernel, dim3(grid_for(Nu * 2 * k, 256)), dim3(256), 0, st, U, U2, Nu, k, w1, w2, ucat);
+            DR_LAUNCH(neg_sqnorm_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, U, U2, Nu, k, w1, w2, uadd);
+            DR_LAUNCH(concat_scale_kernel, dim3(grid_for(Nu * 2 * k, 256)), dim3(256), 0, st, U, U2, Nu, k, w1, w2, ucat);
         }
         if (Ni > 0) {
-            hipLaunchKernelGGL(neg_sqnorm_kernel, dim3(grid_for(Ni, 256)), dim3(256), 0, st, I, I2, Ni, k, w1, w2, iadd);
-            hipLaunchKernelGGL(concat_scale_kernel, dim3(grid_for(Ni * 2 * k, 256)), dim3(256), 0, st, I, I2, Ni, k, 1.0f, 1.0f, icat);
+            DR_LAUNCH(neg_sqnorm_kernel, dim3(grid_for(Ni, 256)), dim3(256), 0, st, I, I2, Ni, k, w1, w2, iadd);
+            DR_LAUNCH(concat_scale_kernel, dim3(grid_for(Ni * 2 * k, 256)), dim3(256), 0, st, I, I2, Ni, k, 1.0f, 1.0f, icat);
         }
         a->U = ucat;
         a->I = icat;
         a->k = 2 * k;
     }
     if (item_bias && Ni > 0)
-        hipLaunchKernelGGL(add_vec_kernel, dim3(grid_for(Ni, 256)), dim3(256), 0, st, iadd, item_bias, Ni);
+        DR_LAUNCH(add_vec_kernel, dim3(grid_for(Ni, 256)), dim3(256), 0, st, iadd, item_bias, Ni);
     a->uadd = uadd;
     a->iadd = iadd;
     DR_CHECK_LAUNCH("score operand preparation");
@@ -560,7 +560,7 @@ extern "C" int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu
         a.tgt_score = (float*)(base + L.tgt_score);
         a.tgt_masked = (int32_t*)(base + L.tgt_masked);
         a.tgt_rank = tgt_rank;
-        hipLaunchKernelGGL(target_prologue_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, a.U, a.I, a.uadd, a.iadd,
+        DR_LAUNCH(target_prologue_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, a.U, a.I, a.uadd, a.iadd,
                            a.cdot, Nu, Ni, a.k, (const float*)nullptr, train_ptr, train_idx, tgt_ptr, tgt_idx,
                            (float*)(base + L.tgt_score), (int32_t*)(base + L.tgt_masked), tgt_rank);
         DR_CHECK_LAUNCH("target_prologue_kernel");
@@ -569,13 +569,13 @@ extern "C" int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu
     DR_HIP(hipFuncSetAttribute((const void*)score_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int64_t panels = (Nu + TU - 1) / TU;
     DR_REQUIRE(panels < (1ll << 31), "dr_score_topk_f32: too many user panels");
-    hipLaunchKernelGGL((score_kernel<false>), dim3((unsigned)panels, (unsigned)L.S), dim3(256), smem, st, a);
+    DR_LAUNCH((score_kernel<false>), dim3((unsigned)panels, (unsigned)L.S), dim3(256), smem, st, a);
     DR_CHECK_LAUNCH("score_kernel");
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, a.part_v, a.part_i, L.S, Nu, K,
+    DR_LAUNCH(topk_merge_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, a.part_v, a.part_i, L.S, Nu, K,
                        topk_idx, topk_score);
     DR_CHECK_LAUNCH("topk_merge_kernel");
     if (n_targets > 0) {
-        hipLaunchKernelGGL(target_finalize_kernel, dim3(grid_for(n_targets, 256)), dim3(256), 0, st,
+        DR_LAUNCH(target_finalize_kernel, dim3(grid_for(n_targets, 256)), dim3(256), 0, st,
                            (const int32_t*)(base + L.tgt_masked), n_targets, tgt_rank);
         DR_CHECK_LAUNCH("target_finalize_kernel");
     }
@@ -618,7 +618,7 @@ extern "C" int32_t dr_score_matrix_f32(const float* U, const float* U2, int64_t 
     S = (L.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
     const size_t smem = score_smem_bytes(1);
     DR_HIP(hipFuncSetAttribute((const void*)score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((score_kernel<true>), dim3((unsigned)panels, (unsigned)S), dim3(256), smem, st, a);
+    DR_LAUNCH((score_kernel<true>), dim3((unsigned)panels, (unsigned)S), dim3(256), smem, st, a);
     DR_CHECK_LAUNCH("score_kernel<matrix>");
     return DR_OK;
 }
@@ -644,18 +644,18 @@ extern "C" int32_t dr_topk_rank_f32(const float* scores, int64_t Nu, int64_t Ni,
                     (long long)need);
         tgt_score = (float*)ws;
         tgt_masked = (int32_t*)((char*)ws + align_up(n_targets * 4, 256));
-        hipLaunchKernelGGL(target_prologue_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, (const float*)nullptr,
+        DR_LAUNCH(target_prologue_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1.0f, Nu, Ni, 0, scores,
                            train_ptr, train_idx, tgt_ptr, tgt_idx, tgt_score, tgt_masked, tgt_rank);
         DR_CHECK_LAUNCH("target_prologue_kernel");
     }
     int grid = (int)(Nu < 256 * 8 ? Nu : 256 * 8);
-    hipLaunchKernelGGL(topk_rank_matrix_kernel, dim3(grid), dim3(256), 0, st, scores, Nu, Ni, train_ptr, train_idx,
+    DR_LAUNCH(topk_rank_matrix_kernel, dim3(grid), dim3(256), 0, st, scores, Nu, Ni, train_ptr, train_idx,
                        n_targets > 0 ? tgt_ptr : nullptr, tgt_idx, tgt_score, tgt_masked, K, topk_idx, topk_score,
                        tgt_rank);
     DR_CHECK_LAUNCH("topk_rank_matrix_kernel");
     if (n_targets > 0) {
-        hipLaunchKernelGGL(target_finalize_kernel, dim3(grid_for(n_targets, 256)), dim3(256), 0, st, tgt_masked,
+        DR_LAUNCH(target_finalize_kernel, dim3(grid_for(n_targets, 256)), dim3(256), 0, st, tgt_masked,
                            n_targets, tgt_rank);
         DR_CHECK_LAUNCH("target_finalize_kernel");
     }

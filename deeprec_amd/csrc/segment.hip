@@ -18,9 +18,16 @@ namespace dr {
 // ---------------------------------------------------------------------------------------
 struct PlanLayout {
     int64_t hdr, keys_in, keys_out, vals_in, vals_out, flags, segidx, uniq, seg_start, temp, temp_bytes, total;
+    int64_t long_seg, long_cb, part_owner, partials, partial_rows;
 };
 
-static int plan_layout(int64_t n, PlanLayout* L, char* err) {
+// Segments longer than LONG_SEG contributions are summed in two passes so that a popular row does not
+// serialise the launch: seg_long_partial_kernel gives every DR_SEG_CHUNK-block of every long segment its
+// own sub-wave (block partials parked in the plan's scratch), seg_long_combine_kernel adds a segment's
+// partials in block order and applies the update -- the same blocked position order, in parallel.
+constexpr int LONG_SEG = 2 * DR_SEG_CHUNK;
+
+static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
     size_t t_sort = 0, t_scan = 0;
     int64_t nn = n > 0 ? n : 1;
     hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, int32_t*, int32_t*>(
@@ -52,13 +59,24 @@ static int plan_layout(int64_t n, PlanLayout* L, char* err) {
     L->seg_start = take((nn + 1) * 4);
     L->temp_bytes = (int64_t)(t_sort > t_scan ? t_sort : t_scan) + 256;
     L->temp = take(L->temp_bytes);
+    const int64_t max_long = nn / LONG_SEG + 1;
+    L->long_seg = take(max_long * 4);
+    L->long_cb = take(max_long * 4);
+    L->partial_rows = nn / DR_SEG_CHUNK + max_long + 1;
+    L->part_owner = take(L->partial_rows * 4);
+    L->partials = take(L->partial_rows * (int64_t)(k_max > 0 ? k_max : 1) * 4);
     L->total = off;
     return 0;
 }
 
 template <typename IdT>
 __global__ __launch_bounds__(256) void plan_keys_kernel(const IdT* __restrict__ ids, int64_t n, int64_t rows,
-                                                        uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+                                                        uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                        int32_t* __restrict__ hdr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr[1] = 0;  // number of long segments
+        hdr[2] = 0;  // partial rows handed out
+    }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         int64_t id = (int64_t)ids[e];
         keys[e] = (id < 0 || id >= rows) ? (uint32_t)rows : (uint32_t)id;  // out-of-range -> sentinel `rows`
@@ -92,7 +110,28 @@ __global__ __launch_bounds__(256) void plan_finalize_kernel(const uint32_t* __re
 
 __global__ void plan_empty_kernel(int32_t* hdr, int32_t* seg_start) {
     hdr[0] = 0;
+    hdr[1] = 0;
+    hdr[2] = 0;
     seg_start[0] = 0;
+}
+
+// list the long segments and hand each a contiguous range of partial rows (allocation order is
+// arbitrary; it never influences a result)
+__global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restrict__ seg_start, int32_t* __restrict__ hdr,
+                                                        int32_t* __restrict__ long_seg, int32_t* __restrict__ long_cb,
+                                                        int32_t* __restrict__ part_owner, int64_t n) {
+    const int nseg = hdr[0];
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * 256) {
+        const int len = seg_start[s + 1] - seg_start[s];
+        if (len > LONG_SEG) {
+            const int l = atomicAdd(&hdr[1], 1);
+            const int nch = (len + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK;
+            const int cb = atomicAdd(&hdr[2], nch);
+            long_seg[l] = (int32_t)s;
+            long_cb[l] = cb;
+            for (int c = 0; c < nch; ++c) part_owner[cb + c] = l;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -113,90 +152,193 @@ struct SegArgs {
     const int32_t* sorted_pos;
     const int32_t* uniq;
     const int32_t* seg_start;
-    const int32_t* nseg;
+    const int32_t* hdr;       // [0] nseg, [1] n long segments
+    const int32_t* long_seg;
+    const int32_t* long_cb;
+    const int32_t* part_owner;
+    float* partials;
     int kind;
     OptP opt;
 };
 
+// sum of contributions [y0, y1) (one DR_SEG_CHUNK block) for vector column c, sequential in y;
+// the row loads of a block are independent of the running sum, so they are issued 4 at a time
+template <int V>
+__device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int c, float (&acc)[V]) {
+#pragma unroll
+    for (int x = 0; x < V; ++x) acc[x] = 0.0f;
+    int y = y0;
+    for (; y + 4 <= y1; y += 4) {
+        float v[4][V];
+        float cf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = a.sorted_pos[y + q];
+            const int64_t si = a.src_idx ? (int64_t)a.src_idx[p] : (int64_t)p;
+            cf[q] = a.coef ? a.coef[p] : 1.0f;
+            if (si >= 0 && si < a.src_rows) {
+                vload<V>(v[q], a.src + si * a.k + c * V);
+            } else {
+                cf[q] = 0.0f;
+#pragma unroll
+                for (int x = 0; x < V; ++x) v[q][x] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int x = 0; x < V; ++x) acc[x] = acc[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
+        }
+    }
+    for (; y < y1; ++y) {
+        const int p = a.sorted_pos[y];
+        const int64_t si = a.src_idx ? (int64_t)a.src_idx[p] : (int64_t)p;
+        if (si < 0 || si >= a.src_rows) continue;
+        float v[V];
+        vload<V>(v, a.src + si * a.k + c * V);
+        if (a.coef) {
+            const float cf = a.coef[p];
+#pragma unroll
+            for (int x = 0; x < V; ++x) v[x] = cf * v[x];
+        }
+#pragma unroll
+        for (int x = 0; x < V; ++x) acc[x] = acc[x] + v[x];
+    }
+}
+
+// gradient total -> destination row (accumulate, or L2 + optimizer application)
+template <int V>
+__device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, float (&tot)[V]) {
+    const int64_t off = (int64_t)r * a.k + c * V;
+    float w[V], s0[V], s1[V];
+    vload<V>(w, a.table + off);
+    if (a.kind == KIND_ACC) {
+#pragma unroll
+        for (int x = 0; x < V; ++x) w[x] = w[x] + tot[x];
+        vstore<V>(a.table + off, w);
+        return;
+    }
+    if (a.opt.reg_mode == DR_REG_TOUCHED) {
+#pragma unroll
+        for (int x = 0; x < V; ++x) tot[x] = tot[x] + a.opt.reg * w[x];
+    }
+    switch (a.kind) {
+        case DR_OPT_SGD:
+#pragma unroll
+            for (int x = 0; x < V; ++x) opt_apply<DR_OPT_SGD>(w[x], s0[x], s1[x], tot[x], a.opt);
+            break;
+        case DR_OPT_ADAM:
+            vload<V>(s0, a.slot0 + off);
+            vload<V>(s1, a.slot1 + off);
+#pragma unroll
+            for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAM>(w[x], s0[x], s1[x], tot[x], a.opt);
+            vstore<V>(a.slot0 + off, s0);
+            vstore<V>(a.slot1 + off, s1);
+            break;
+        case DR_OPT_ADAGRAD:
+            vload<V>(s0, a.slot0 + off);
+#pragma unroll
+            for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAGRAD>(w[x], s0[x], s1[x], tot[x], a.opt);
+            vstore<V>(a.slot0 + off, s0);
+            break;
+        default:
+            vload<V>(s0, a.slot0 + off);
+            vload<V>(s1, a.slot1 + off);
+#pragma unroll
+            for (int x = 0; x < V; ++x) opt_apply<DR_OPT_RMSPROP>(w[x], s0[x], s1[x], tot[x], a.opt);
+            vstore<V>(a.slot0 + off, s0);
+            vstore<V>(a.slot1 + off, s1);
+            break;
+    }
+    vstore<V>(a.table + off, w);
+}
+
+// short segments: one sub-wave per segment
 template <int V, int LPR>
 __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
     constexpr int SPB = 256 / LPR;  // segments per block pass
     const int sub = threadIdx.x / LPR;
     const int lane = threadIdx.x % LPR;
     const int cpr = a.k / V;
-    const int nseg = *a.nseg;
+    const int nseg = a.hdr[0];
     for (int s = blockIdx.x * SPB + sub; s < nseg; s += gridDim.x * SPB) {
         const uint32_t r = (uint32_t)a.uniq[s];
         if ((int64_t)r >= a.rows) continue;  // sentinel segment of out-of-range ids
         const int b = a.seg_start[s], e = a.seg_start[s + 1];
+        if (e - b > LONG_SEG) continue;      // seg_long_kernel's
+        for (int c = lane; c < cpr; c += LPR) {
+            float tot[V], acc[V];
+#pragma unroll
+            for (int x = 0; x < V; ++x) tot[x] = 0.0f;
+            for (int c0 = b; c0 < e; c0 += DR_SEG_CHUNK) {
+                block_sum<V>(a, c0, (c0 + DR_SEG_CHUNK < e) ? c0 + DR_SEG_CHUNK : e, c, acc);
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = tot[x] + acc[x];
+            }
+            apply_row<V>(a, r, c, tot);
+        }
+    }
+}
+
+// long segments, pass 1: one sub-wave per DR_SEG_CHUNK-block of a long segment
+template <int V, int LPR>
+__global__ __launch_bounds__(256) void seg_long_partial_kernel(SegArgs a) {
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int cpr = a.k / V;
+    const int nparts = a.hdr[2];
+    for (int pr = blockIdx.x * SPB + sub; pr < nparts; pr += gridDim.x * SPB) {
+        const int l = a.part_owner[pr];
+        const int s = a.long_seg[l];
+        const int ch = pr - a.long_cb[l];
+        const int b = a.seg_start[s], e = a.seg_start[s + 1];
+        const int c0 = b + ch * DR_SEG_CHUNK;
+        const int c1 = (c0 + DR_SEG_CHUNK < e) ? c0 + DR_SEG_CHUNK : e;
+        for (int c = lane; c < cpr; c += LPR) {
+            float acc[V];
+            block_sum<V>(a, c0, c1, c, acc);
+            vstore<V>(a.partials + (int64_t)pr * a.k + c * V, acc);
+        }
+    }
+}
+
+// long segments, pass 2: one sub-wave per long segment adds its block partials in block order
+template <int V, int LPR>
+__global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int cpr = a.k / V;
+    const int nlong = a.hdr[1];
+    for (int l = blockIdx.x * SPB + sub; l < nlong; l += gridDim.x * SPB) {
+        const int s = a.long_seg[l];
+        const uint32_t r = (uint32_t)a.uniq[s];
+        if ((int64_t)r >= a.rows) continue;
+        const int nch = (a.seg_start[s + 1] - a.seg_start[s] + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK;
+        const float* part = a.partials + (int64_t)a.long_cb[l] * a.k;
         for (int c = lane; c < cpr; c += LPR) {
             float tot[V];
 #pragma unroll
             for (int x = 0; x < V; ++x) tot[x] = 0.0f;
-            for (int c0 = b; c0 < e; c0 += DR_SEG_CHUNK) {
-                float acc[V];
+            int ch = 0;
+            for (; ch + 8 <= nch; ch += 8) {
+                float v[8][V];
 #pragma unroll
-                for (int x = 0; x < V; ++x) acc[x] = 0.0f;
-                const int ce = (c0 + DR_SEG_CHUNK < e) ? c0 + DR_SEG_CHUNK : e;
-                for (int y = c0; y < ce; ++y) {
-                    const int p = a.sorted_pos[y];
-                    const int64_t si = a.src_idx ? (int64_t)a.src_idx[p] : (int64_t)p;
-                    if (si < 0 || si >= a.src_rows) continue;
-                    float v[V];
-                    vload<V>(v, a.src + si * a.k + c * V);
-                    if (a.coef) {
-                        const float cf = a.coef[p];
+                for (int q = 0; q < 8; ++q) vload<V>(v[q], part + (int64_t)(ch + q) * a.k + c * V);
 #pragma unroll
-                        for (int x = 0; x < V; ++x) v[x] = cf * v[x];
-                    }
+                for (int q = 0; q < 8; ++q) {
 #pragma unroll
-                    for (int x = 0; x < V; ++x) acc[x] = acc[x] + v[x];
+                    for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[q][x];
                 }
-#pragma unroll
-                for (int x = 0; x < V; ++x) tot[x] = tot[x] + acc[x];
             }
-            const int64_t off = (int64_t)r * a.k + c * V;
-            float w[V], s0[V], s1[V];
-            vload<V>(w, a.table + off);
-            if (a.kind == KIND_ACC) {
+            for (; ch < nch; ++ch) {
+                float v[V];
+                vload<V>(v, part + (int64_t)ch * a.k + c * V);
 #pragma unroll
-                for (int x = 0; x < V; ++x) w[x] = w[x] + tot[x];
-                vstore<V>(a.table + off, w);
-                continue;
+                for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[x];
             }
-            if (a.opt.reg_mode == DR_REG_TOUCHED) {
-#pragma unroll
-                for (int x = 0; x < V; ++x) tot[x] = tot[x] + a.opt.reg * w[x];
-            }
-            switch (a.kind) {
-                case DR_OPT_SGD:
-#pragma unroll
-                    for (int x = 0; x < V; ++x) opt_apply<DR_OPT_SGD>(w[x], s0[x], s1[x], tot[x], a.opt);
-                    break;
-                case DR_OPT_ADAM:
-                    vload<V>(s0, a.slot0 + off);
-                    vload<V>(s1, a.slot1 + off);
-#pragma unroll
-                    for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAM>(w[x], s0[x], s1[x], tot[x], a.opt);
-                    vstore<V>(a.slot0 + off, s0);
-                    vstore<V>(a.slot1 + off, s1);
-                    break;
-                case DR_OPT_ADAGRAD:
-                    vload<V>(s0, a.slot0 + off);
-#pragma unroll
-                    for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAGRAD>(w[x], s0[x], s1[x], tot[x], a.opt);
-                    vstore<V>(a.slot0 + off, s0);
-                    break;
-                default:
-                    vload<V>(s0, a.slot0 + off);
-                    vload<V>(s1, a.slot1 + off);
-#pragma unroll
-                    for (int x = 0; x < V; ++x) opt_apply<DR_OPT_RMSPROP>(w[x], s0[x], s1[x], tot[x], a.opt);
-                    vstore<V>(a.slot0 + off, s0);
-                    vstore<V>(a.slot1 + off, s1);
-                    break;
-            }
-            vstore<V>(a.table + off, w);
+            apply_row<V>(a, r, c, tot);
         }
     }
 }
@@ -205,7 +347,13 @@ template <int V, int LPR>
 static void launch_seg(const SegArgs& a, int64_t n, hipStream_t st) {
     constexpr int SPB = 256 / LPR;
     int grid = grid_for(n, 1, SPB);
-    hipLaunchKernelGGL((seg_update_kernel<V, LPR>), dim3(grid), dim3(256), 0, st, a);
+    DR_LAUNCH((seg_update_kernel<V, LPR>), dim3(grid), dim3(256), 0, st, a);
+    if (n > LONG_SEG) {
+        // partial rows <= n / DR_SEG_CHUNK + n / LONG_SEG ; long segments <= n / LONG_SEG
+        DR_LAUNCH((seg_long_partial_kernel<V, LPR>), dim3(grid_for(n / DR_SEG_CHUNK + n / LONG_SEG + 1, 1, SPB)),
+                  dim3(256), 0, st, a);
+        DR_LAUNCH((seg_long_combine_kernel<V, LPR>), dim3(grid_for(n / LONG_SEG + 1, 1, SPB)), dim3(256), 0, st, a);
+    }
 }
 
 static int dispatch_seg(const SegArgs& a, int64_t n, hipStream_t st) {
@@ -280,10 +428,10 @@ __global__ __launch_bounds__(256) void rownorm_clip_kernel(float* __restrict__ t
 
 using namespace dr;
 
-extern "C" int64_t dr_segment_plan_bytes(int64_t n) {
-    if (n < 0) return DR_ERR_ARG;
+extern "C" int64_t dr_segment_plan_bytes(int64_t n, int32_t k_max) {
+    if (n < 0 || k_max < 1) return DR_ERR_ARG;
     PlanLayout L;
-    if (plan_layout(n, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_layout(n, k_max, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
     return L.total;
 }
 
@@ -295,7 +443,7 @@ extern "C" int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, 
     DR_REQUIRE(plan != nullptr && ((uintptr_t)plan % 256 == 0), "dr_segment_plan: plan must be 256-byte aligned");
     DR_REQUIRE(ids != nullptr || n == 0, "dr_segment_plan: ids is NULL");
     PlanLayout L;
-    if (plan_layout(n, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_layout(n, 1, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
     if (plan_bytes < L.total)
         DR_FAIL(DR_ERR_WORKSPACE, "dr_segment_plan: workspace %lld < required %lld", (long long)plan_bytes,
                 (long long)L.total);
@@ -311,31 +459,37 @@ extern "C" int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, 
     int32_t* uniq = (int32_t*)(base + L.uniq);
     int32_t* seg_start = (int32_t*)(base + L.seg_start);
     if (n == 0) {
-        hipLaunchKernelGGL(plan_empty_kernel, dim3(1), dim3(1), 0, st, hdr, seg_start);
+        DR_LAUNCH(plan_empty_kernel, dim3(1), dim3(1), 0, st, hdr, seg_start);
         DR_CHECK_LAUNCH("dr_segment_plan(empty)");
         return DR_OK;
     }
     int grid = grid_for(n, 256);
     if (id_bits == 32)
-        hipLaunchKernelGGL((plan_keys_kernel<int32_t>), dim3(grid), dim3(256), 0, st, (const int32_t*)ids, n, rows,
-                           keys_in, vals_in);
+        DR_LAUNCH((plan_keys_kernel<int32_t>), dim3(grid), dim3(256), 0, st, (const int32_t*)ids, n, rows,
+                           keys_in, vals_in, hdr);
     else
-        hipLaunchKernelGGL((plan_keys_kernel<int64_t>), dim3(grid), dim3(256), 0, st, (const int64_t*)ids, n, rows,
-                           keys_in, vals_in);
+        DR_LAUNCH((plan_keys_kernel<int64_t>), dim3(grid), dim3(256), 0, st, (const int64_t*)ids, n, rows,
+                           keys_in, vals_in, hdr);
     DR_CHECK_LAUNCH("plan_keys_kernel");
     unsigned end_bit = 1;
     while (end_bit < 32 && ((uint64_t)rows >> end_bit) != 0) ++end_bit;  // enough bits for the sentinel `rows`
     size_t tb = (size_t)L.temp_bytes;
     DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, keys_in, keys_out, vals_in,
                                                                vals_out, (size_t)n, 0u, end_bit, st, false)));
-    hipLaunchKernelGGL(plan_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, flags);
+    DR_LAUNCH(plan_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, flags);
     DR_CHECK_LAUNCH("plan_heads_kernel");
     tb = (size_t)L.temp_bytes;
     DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, segidx, (int32_t)0, (size_t)n,
                                                              rocprim::plus<int32_t>(), st, false)));
-    hipLaunchKernelGGL(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start,
+    DR_LAUNCH(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start,
                        hdr);
     DR_CHECK_LAUNCH("plan_finalize_kernel");
+    if (n > LONG_SEG) {
+        DR_LAUNCH(plan_long_kernel, dim3(grid), dim3(256), 0, st, seg_start, hdr,
+                           (int32_t*)(base + L.long_seg), (int32_t*)(base + L.long_cb),
+                           (int32_t*)(base + L.part_owner), n);
+        DR_CHECK_LAUNCH("plan_long_kernel");
+    }
     return DR_OK;
 }
 
@@ -343,7 +497,7 @@ extern "C" int32_t dr_segment_plan_view(void* plan, int64_t n, const int32_t** s
                                         const int32_t** seg_start, const int32_t** num_segments) {
     DR_REQUIRE(plan != nullptr && n >= 0, "dr_segment_plan_view: bad arguments");
     PlanLayout L;
-    if (plan_layout(n, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_layout(n, 1, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
     char* base = (char*)plan;
     if (sorted_pos) *sorted_pos = (const int32_t*)(base + L.vals_out);
     if (uniq_ids) *uniq_ids = (const int32_t*)(base + L.uniq);
@@ -355,10 +509,13 @@ extern "C" int32_t dr_segment_plan_view(void* plan, int64_t n, const int32_t** s
 namespace dr {
 // shared by scatter-add, sparse update and the fused steps
 int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
-               const int32_t* src_idx, const float* coef, int64_t n, void* plan, int kind, const dr_opt_params* opt,
-               hipStream_t st) {
+               const int32_t* src_idx, const float* coef, int64_t n, void* plan, int64_t plan_bytes, int kind,
+               const dr_opt_params* opt, hipStream_t st) {
     PlanLayout L;
-    if (plan_layout(n, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "segment kernel: plan workspace %lld < dr_segment_plan_bytes(n=%lld, k=%d) = %lld",
+                (long long)plan_bytes, (long long)n, k, (long long)L.total);
     char* base = (char*)plan;
     SegArgs a;
     a.table = table;
@@ -373,7 +530,11 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
     a.sorted_pos = (const int32_t*)(base + L.vals_out);
     a.uniq = (const int32_t*)(base + L.uniq);
     a.seg_start = (const int32_t*)(base + L.seg_start);
-    a.nseg = (const int32_t*)(base + L.hdr);
+    a.hdr = (const int32_t*)(base + L.hdr);
+    a.long_seg = (const int32_t*)(base + L.long_seg);
+    a.long_cb = (const int32_t*)(base + L.long_cb);
+    a.part_owner = (const int32_t*)(base + L.part_owner);
+    a.partials = (float*)(base + L.partials);
     a.kind = kind;
     if (opt) a.opt = make_optp(opt);
     else memset(&a.opt, 0, sizeof(a.opt));
@@ -396,18 +557,18 @@ int check_opt(const dr_opt_params* opt, const float* slot0, const float* slot1, 
 
 extern "C" int32_t dr_scatter_add_sorted_f32(float* gtable, int64_t rows, int32_t k, const float* src,
                                              int64_t src_rows, const int32_t* src_idx, const float* coef, int64_t n,
-                                             void* plan, void* stream) {
+                                             void* plan, int64_t plan_bytes, void* stream) {
     DR_REQUIRE(rows >= 0 && k >= 1 && n >= 0 && src_rows >= 0, "dr_scatter_add_sorted_f32: bad sizes");
     if (n == 0) return DR_OK;
     DR_REQUIRE(gtable && src && plan, "dr_scatter_add_sorted_f32: NULL pointer");
-    return seg_launch(gtable, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, KIND_ACC, nullptr,
-                      (hipStream_t)stream);
+    return seg_launch(gtable, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, KIND_ACC,
+                      nullptr, (hipStream_t)stream);
 }
 
 extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* slot1, int64_t rows, int32_t k,
                                             const float* src, int64_t src_rows, const int32_t* src_idx,
-                                            const float* coef, int64_t n, void* plan, const dr_opt_params* opt,
-                                            void* stream) {
+                                            const float* coef, int64_t n, void* plan, int64_t plan_bytes,
+                                            const dr_opt_params* opt, void* stream) {
     DR_REQUIRE(rows >= 0 && k >= 1 && n >= 0 && src_rows >= 0, "dr_sparse_row_update_f32: bad sizes");
     int rc = check_opt(opt, slot0, slot1, "dr_sparse_row_update_f32");
     if (rc != DR_OK) return rc;
@@ -415,7 +576,7 @@ extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* s
                "dr_sparse_row_update_f32: DR_REG_DENSE is served by dr_scatter_add_sorted_f32 + dr_dense_update_f32");
     if (n == 0) return DR_OK;
     DR_REQUIRE(table && src && plan, "dr_sparse_row_update_f32: NULL pointer");
-    return seg_launch(table, slot0, slot1, rows, k, src, src_rows, src_idx, coef, n, plan, opt->kind, opt,
+    return seg_launch(table, slot0, slot1, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, opt->kind, opt,
                       (hipStream_t)stream);
 }
 
@@ -431,19 +592,19 @@ extern "C" int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, con
     int grid = grid_for(count, 256, 4);
     switch (opt->kind) {
         case DR_OPT_SGD:
-            hipLaunchKernelGGL((dense_update_kernel<DR_OPT_SGD>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad,
+            DR_LAUNCH((dense_update_kernel<DR_OPT_SGD>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad,
                                count, o);
             break;
         case DR_OPT_ADAM:
-            hipLaunchKernelGGL((dense_update_kernel<DR_OPT_ADAM>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad,
+            DR_LAUNCH((dense_update_kernel<DR_OPT_ADAM>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad,
                                count, o);
             break;
         case DR_OPT_ADAGRAD:
-            hipLaunchKernelGGL((dense_update_kernel<DR_OPT_ADAGRAD>), dim3(grid), dim3(256), 0, st, w, slot0, slot1,
+            DR_LAUNCH((dense_update_kernel<DR_OPT_ADAGRAD>), dim3(grid), dim3(256), 0, st, w, slot0, slot1,
                                grad, count, o);
             break;
         default:
-            hipLaunchKernelGGL((dense_update_kernel<DR_OPT_RMSPROP>), dim3(grid), dim3(256), 0, st, w, slot0, slot1,
+            DR_LAUNCH((dense_update_kernel<DR_OPT_RMSPROP>), dim3(grid), dim3(256), 0, st, w, slot0, slot1,
                                grad, count, o);
             break;
     }
@@ -460,7 +621,7 @@ extern "C" int32_t dr_rownorm_clip_f32(float* table, int64_t rows, int32_t k, fl
     bool ok = false;
 #define DR_C(V_, L_)                                                                                            \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                      \
-        hipLaunchKernelGGL((rownorm_clip_kernel<V_, L_>), dim3(grid_for(rows, 1, 256 / L_)), dim3(256), 0, st,  \
+        DR_LAUNCH((rownorm_clip_kernel<V_, L_>), dim3(grid_for(rows, 1, 256 / L_)), dim3(256), 0, st,  \
                            table, rows, k, clip);                                                               \
         ok = true;                                                                                              \
     }

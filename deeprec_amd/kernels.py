@@ -97,11 +97,12 @@ def scale_rows(src, coef, idx=None):
 class SegmentPlan:
     """Stable sort of an id list + run boundaries, held in a device workspace."""
 
-    def __init__(self, ids, rows, workspace=None):
+    def __init__(self, ids, rows, workspace=None, k_max=128):
         ids, bits = _ids(ids, "ids")
         self.n = ids.numel()
         self.rows = int(rows)
-        need = check(_abi.lib().dr_segment_plan_bytes(self.n), "dr_segment_plan_bytes")
+        self.k_max = int(k_max)
+        need = check(_abi.lib().dr_segment_plan_bytes(self.n, self.k_max), "dr_segment_plan_bytes")
         if workspace is None:
             workspace = torch.empty(need, dtype=torch.uint8, device=ids.device)
         if workspace.numel() < need or workspace.data_ptr() % 256:
@@ -142,11 +143,12 @@ def scatter_add(gtable, ids, src, src_idx=None, coef=None, plan=None):
     if coef is not None and _req(coef, torch.float32, "coef").numel() != n:
         raise ValueError("coef must have one entry per id")
     if plan is None:
-        plan = SegmentPlan(ids, gtable.shape[0])
+        plan = SegmentPlan(ids, gtable.shape[0], k_max=k)
     if plan.n != n or plan.rows != gtable.shape[0]:
         raise ValueError("plan was built for a different id list / table")
     check(_abi.lib().dr_scatter_add_sorted_f32(_ptr(gtable), gtable.shape[0], k, _ptr(src), src_rows, _ptr(src_idx),
-                                               _ptr(coef), n, _ptr(plan.ws), _stream()), "dr_scatter_add_sorted_f32")
+                                               _ptr(coef), n, _ptr(plan.ws), plan.ws.numel(), _stream()),
+          "dr_scatter_add_sorted_f32")
     return gtable
 
 
@@ -173,10 +175,10 @@ def sparse_row_update(table, slot0, slot1, ids, src, opt, src_idx=None, coef=Non
     if coef is not None:
         _req(coef, torch.float32, "coef")
     if plan is None:
-        plan = SegmentPlan(ids, table.shape[0])
+        plan = SegmentPlan(ids, table.shape[0], k_max=k)
     check(_abi.lib().dr_sparse_row_update_f32(_ptr(table), _ptr(slot0), _ptr(slot1), table.shape[0], k, _ptr(src),
-                                              src_rows, _ptr(src_idx), _ptr(coef), n, _ptr(plan.ws), C.byref(opt),
-                                              _stream()), "dr_sparse_row_update_f32")
+                                              src_rows, _ptr(src_idx), _ptr(coef), n, _ptr(plan.ws), plan.ws.numel(),
+                                              C.byref(opt), _stream()), "dr_sparse_row_update_f32")
     return table
 
 

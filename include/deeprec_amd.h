@@ -94,8 +94,9 @@ int32_t dr_scale_rows_f32(const float* src, int64_t src_rows, int32_t k, const i
  * cml.py:79, mf.py:103, nfm.py:82, nnmf.py:84, Caser.py:85, AttRec.py:110, PRME.py:98).
  *
  * A "segment plan" is the stable sort of an id list plus its run boundaries; it lives
- * in a caller-provided workspace and is consumed by the kernels below. */
-int64_t dr_segment_plan_bytes(int64_t n);
+ * in a caller-provided workspace (sized for rows of up to k_max floats: it also holds the
+ * block partials of long segments) and is consumed by the kernels below. */
+int64_t dr_segment_plan_bytes(int64_t n, int32_t k_max);
 int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, int64_t rows, void* plan,
                         int64_t plan_bytes, void* stream);
 /* Device pointers into a built plan (valid until the workspace is reused). */
@@ -108,7 +109,7 @@ int32_t dr_segment_plan_view(void* plan, int64_t n, const int32_t** sorted_pos,
  * outside [0, src_rows) and destinations outside [0, rows) are skipped. */
 int32_t dr_scatter_add_sorted_f32(float* gtable, int64_t rows, int32_t k, const float* src,
                                   int64_t src_rows, const int32_t* src_idx, const float* coef,
-                                  int64_t n, void* plan, void* stream);
+                                  int64_t n, void* plan, int64_t plan_bytes, void* stream);
 
 /* ---- K5: sparse row update ------------------------------------------------------
  * Replaces Optimizer.apply_gradients / minimize on embedding tables (same call sites
@@ -119,8 +120,8 @@ int32_t dr_scatter_add_sorted_f32(float* gtable, int64_t rows, int32_t k, const 
  * DR_REG_DENSE is served by dr_dense_update_f32 over a dense gradient instead. */
 int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* slot1, int64_t rows, int32_t k,
                                  const float* src, int64_t src_rows, const int32_t* src_idx,
-                                 const float* coef, int64_t n, void* plan, const dr_opt_params* opt,
-                                 void* stream);
+                                 const float* coef, int64_t n, void* plan, int64_t plan_bytes,
+                                 const dr_opt_params* opt, void* stream);
 
 /* Whole-tensor optimizer application: g = grad[i] (may be NULL = 0) + reg*w[i].
  * Serves DR_REG_DENSE tables (bprmf.py:118-122: the l2_loss term makes the table
