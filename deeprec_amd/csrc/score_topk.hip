@@ -20,7 +20,7 @@ constexpr int TI = 64;   // items per tile step
 constexpr int KC = 128;  // k-chunk staged in LDS
 constexpr int LDK = KC + 1;
 constexpr int LDS_S = TI + 1;
-constexpr int MAXK_TOP = 128;
+constexpr int MAXK_TOP = 100;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -62,6 +62,31 @@ __device__ __forceinline__ float score_epilogue(float acc, float cdot, const flo
     return s;
 }
 
+constexpr int TCAP = 1024;  // held-out items of one 64-user panel cached in LDS (more: read from global)
+
+// Stage a [64 rows x kce] operand chunk into LDS (row stride LDK).  Global reads are float4 along k when
+// the row stride allows it; LDS writes are scalar because the padded stride breaks 16-byte alignment.
+__device__ __forceinline__ void stage_chunk(float* __restrict__ dst, const float* __restrict__ src, int64_t row0,
+                                            int64_t nrows, int k, int kc0, int kcn, int kce, int tid) {
+    if ((k & 3) == 0 && (kcn & 3) == 0) {
+        const int gpr = kcn >> 2;  // float4 groups per row
+        for (int e = tid; e < 64 * gpr; e += 256) {
+            const int r = e / gpr, g = e - r * gpr;
+            const int64_t row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nrows) v = *reinterpret_cast<const float4*>(src + row * k + kc0 + g * 4);
+            float* d = dst + r * LDK + g * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int e = tid; e < 64 * kce; e += 256) {
+            const int r = e / kce, c = e - r * kce;
+            const int64_t row = row0 + r;
+            dst[r * LDK + c] = (row < nrows && c < kcn) ? src[row * k + kc0 + c] : 0.0f;
+        }
+    }
+}
+
 template <bool MATRIX>
 __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
     extern __shared__ __align__(16) float smem[];
@@ -70,6 +95,13 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
     float* sS = sI + TI * LDK;       // [TU][LDS_S]
     float* topv = sS + TU * LDS_S;   // [TU][K]
     int* topi = (int*)(topv + TU * a.K);
+    float* tau = (float*)(topi + TU * a.K);                           // [TU] K-th best so far (NaN: list not full)
+    unsigned long long* maskw = (unsigned long long*)(tau + TU);      // [TU] masked (train) items of this tile
+    unsigned long long* candw = maskw + TU;                           // [TU] columns that beat tau in this tile
+    int* tptr = (int*)(candw + TU);                                   // [TU+1] panel-local target offsets
+    float* tsc_l = (float*)(tptr + TU + 1);                           // [TCAP]
+    int* tid_l = (int*)(tsc_l + TCAP);                                // [TCAP] item id, -1 = masked target
+    int* tcnt_l = tid_l + TCAP;                                       // [TCAP]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -81,19 +113,25 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
     if (t_end > a.ntiles) t_end = a.ntiles;
     const int K = a.K;
 
-    // per-row selection state lives with thread `tid` < TU
+    // ---- selection state -------------------------------------------------------------------
     const int64_t myu = u0 + tid;
     const bool rowthread = (!MATRIX) && tid < TU && myu < a.Nu;
-    int cur = 0, cur_end = 0;
+    int cur = 0, cur_end = 0, nxt = 0x7fffffff;   // train cursor of the row thread, next train item cached
+    int tg0 = 0, ntg = 0;                          // this panel's slice of the target CSR
+    bool tg_lds = false;
     if (!MATRIX) {
         for (int e = tid; e < TU * K; e += 256) {
             topv[e] = -INFINITY;
             topi[e] = 0x7fffffff;
         }
+        if (tid < TU) {
+            tau[tid] = __builtin_nanf("");
+            candw[tid] = 0ull;
+            maskw[tid] = 0ull;
+        }
         if (rowthread && a.train_ptr) {
             cur = a.train_ptr[myu];
             cur_end = a.train_ptr[myu + 1];
-            // first train item >= first item of this split
             const int first = t_begin * TI;
             int lo = cur, hi = cur_end;
             while (lo < hi) {
@@ -101,12 +139,40 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
                 if (a.train_idx[mid] < first) lo = mid + 1; else hi = mid;
             }
             cur = lo;
+            nxt = cur < cur_end ? a.train_idx[cur] : 0x7fffffff;
+        }
+        if (a.tgt_ptr) {
+            const int64_t ulast = (u0 + TU < a.Nu) ? u0 + TU : a.Nu;
+            tg0 = a.tgt_ptr[u0];
+            ntg = a.tgt_ptr[ulast] - tg0;
+            tg_lds = ntg <= TCAP;
+            if (tid <= TU) {
+                const int64_t u = (u0 + tid < a.Nu) ? u0 + tid : a.Nu;
+                tptr[tid] = a.tgt_ptr[u] - tg0;
+            }
+            if (tg_lds)
+                for (int x = tid; x < ntg; x += 256) {
+                    tsc_l[x] = a.tgt_score[tg0 + x];
+                    tid_l[x] = a.tgt_masked[tg0 + x] ? -1 : a.tgt_idx[tg0 + x];
+                    tcnt_l[x] = 0;
+                }
         }
     }
     const bool one_chunk = a.k <= KC;
 
     for (int t = t_begin; t < t_end; ++t) {
         const int64_t i0 = (int64_t)t * TI;
+        // row threads: train-item bitmap of this tile (visible after the staging barrier below)
+        if (rowthread) {
+            unsigned long long m = 0ull;
+            const int hi = (int)i0 + TI;
+            while (nxt < hi) {
+                m |= 1ull << (nxt - (int)i0);
+                ++cur;
+                nxt = cur < cur_end ? a.train_idx[cur] : 0x7fffffff;
+            }
+            maskw[tid] = m;
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -114,22 +180,18 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
             const int kcn = (a.k - kc0 < KC) ? (a.k - kc0) : KC;
             const int kce = (kcn + 1) & ~1;  // even, zero padded
             __syncthreads();
-            if (!(one_chunk && t > t_begin)) {  // the user panel stays resident when k fits one chunk
-                for (int e = tid; e < TU * kce; e += 256) {
-                    const int r = e / kce, c = e - r * kce;
-                    const int64_t u = u0 + r;
-                    sU[r * LDK + c] = (u < a.Nu && c < kcn) ? a.U[u * a.k + kc0 + c] : 0.0f;
-                }
-            }
-            for (int e = tid; e < TI * kce; e += 256) {
-                const int r = e / kce, c = e - r * kce;
-                const int64_t i = i0 + r;
-                sI[r * LDK + c] = (i < a.Ni && c < kcn) ? a.I[i * a.k + kc0 + c] : 0.0f;
-            }
+            if (!(one_chunk && t > t_begin))  // the user panel stays resident when k fits one chunk
+                stage_chunk(sU, a.U, u0, a.Nu, a.k, kc0, kcn, kce, tid);
+            stage_chunk(sI, a.I, i0, a.Ni, a.k, kc0, kcn, kce, tid);
             __syncthreads();
             const float* pa = sU + (wu * 32 + (lane & 31)) * LDK + (lane >> 5);
             const float* pb = sI + (wi * 32 + (lane & 31)) * LDK + (lane >> 5);
-            for (int kk = 0; kk < kce; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
+            if (kce == KC) {
+#pragma unroll 16
+                for (int kk = 0; kk < KC; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
+            } else {
+                for (int kk = 0; kk < kce; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
+            }
         }
         // accumulator -> LDS score tile with the affine epilogue
         {
@@ -155,44 +217,66 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
                     a.out[u * a.Ni + i] = s;
                 }
             }
-        } else if (rowthread) {
-            const float* srow = sS + tid * LDS_S;
-            float* tv = topv + tid * K;
-            int* ti = topi + tid * K;
-            unsigned long long live = 0ull;  // unmasked, non-NaN items of this tile
-            const int nc = (a.Ni - i0 < TI) ? (int)(a.Ni - i0) : TI;
-            for (int c = 0; c < nc; ++c) {
-                const int item = (int)(i0 + c);
-                while (cur < cur_end && a.train_idx[cur] < item) ++cur;
-                if (cur < cur_end && a.train_idx[cur] == item) continue;
-                const float s = srow[c];
-                if (s != s) continue;
-                live |= 1ull << c;
-                if (beats(s, item, tv[K - 1], ti[K - 1])) {
-                    int p = K - 1;
-                    while (p > 0 && beats(s, item, tv[p - 1], ti[p - 1])) {
-                        tv[p] = tv[p - 1];
-                        ti[p] = ti[p - 1];
-                        --p;
+        } else {
+            // (row, quarter) threads: threshold filter for the top-K and rank-of-target counting
+            const int row = tid >> 2, q = tid & 3;
+            const int64_t u = u0 + row;
+            if (u < a.Nu) {
+                const float* srow = sS + row * LDS_S + q * 16;
+                const int nc = (a.Ni - i0 < TI) ? (int)(a.Ni - i0) : TI;
+                unsigned live = 0u, cand = 0u;
+                const unsigned mrow = (unsigned)((maskw[row] >> (q * 16)) & 0xffffull);
+                const float th = tau[row];
+                float sv[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    sv[c] = srow[c];
+                    const bool ok = (q * 16 + c < nc) && !((mrow >> c) & 1u) && (sv[c] == sv[c]);
+                    live |= ok ? (1u << c) : 0u;
+                    cand |= (ok && !(sv[c] <= th)) ? (1u << c) : 0u;
+                }
+                if (cand) atomicOr(&candw[row], (unsigned long long)cand << (q * 16));
+                const int tb = a.tgt_ptr ? tptr[row] : 0, te = a.tgt_ptr ? tptr[row + 1] : 0;
+                for (int x = tb; x < te; ++x) {
+                    const int ct = tg_lds ? tid_l[x] : (a.tgt_masked[tg0 + x] ? -1 : a.tgt_idx[tg0 + x]);
+                    if (ct < 0) continue;
+                    const float st = tg_lds ? tsc_l[x] : a.tgt_score[tg0 + x];
+                    const int item0 = (int)i0 + q * 16;
+                    int cnt = 0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) cnt += (((live >> c) & 1u) && beats(sv[c], item0 + c, st, ct)) ? 1 : 0;
+                    if (cnt) {
+                        if (tg_lds) atomicAdd(&tcnt_l[x], cnt);
+                        else atomicAdd(a.tgt_rank + tg0 + x, cnt);
                     }
-                    tv[p] = s;
-                    ti[p] = item;
                 }
             }
-            if (a.tgt_ptr) {
-                const int tb = a.tgt_ptr[myu], te = a.tgt_ptr[myu + 1];
-                for (int x = tb; x < te; ++x) {
-                    if (a.tgt_masked[x]) continue;
-                    const float st = a.tgt_score[x];
-                    const int ct = a.tgt_idx[x];
-                    int cnt = 0;
-                    unsigned long long m = live;
+            __syncthreads();
+            // row threads: fold this tile's candidates into the sorted top-K list
+            if (rowthread) {
+                unsigned long long m = candw[tid];
+                if (m) {
+                    candw[tid] = 0ull;
+                    const float* srow = sS + tid * LDS_S;
+                    float* tv = topv + tid * K;
+                    int* ti = topi + tid * K;
                     while (m) {
                         const int c = __builtin_ctzll(m);
                         m &= m - 1;
-                        cnt += beats(srow[c], (int)(i0 + c), st, ct) ? 1 : 0;
+                        const float s = srow[c];
+                        const int item = (int)(i0 + c);
+                        if (beats(s, item, tv[K - 1], ti[K - 1])) {
+                            int p = K - 1;
+                            while (p > 0 && beats(s, item, tv[p - 1], ti[p - 1])) {
+                                tv[p] = tv[p - 1];
+                                ti[p] = ti[p - 1];
+                                --p;
+                            }
+                            tv[p] = s;
+                            ti[p] = item;
+                        }
                     }
-                    if (cnt) atomicAdd(a.tgt_rank + x, cnt);
+                    if (ti[K - 1] != 0x7fffffff) tau[tid] = tv[K - 1];
                 }
             }
         }
@@ -208,6 +292,9 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
                 a.part_i[o] = topi[e];
             }
         }
+        if (a.tgt_ptr && tg_lds)
+            for (int x = tid; x < ntg; x += 256)
+                if (tcnt_l[x]) atomicAdd(a.tgt_rank + tg0 + x, tcnt_l[x]);
     }
 }
 
@@ -454,7 +541,11 @@ static void topk_layout(int64_t Nu, int64_t Ni, int k, int K, int64_t ntgt, int 
     L->total = off;
 }
 
-static size_t score_smem_bytes(int K) { return (size_t)(2 * TU * LDK + TU * LDS_S) * 4 + (size_t)TU * K * 8; }
+static size_t score_smem_bytes(int K) {
+    return (size_t)(2 * TU * LDK + TU * LDS_S) * 4 + (size_t)TU * K * 8   // operands, score tile, top-K lists
+           + (size_t)TU * 4 + (size_t)TU * 16 + (size_t)(TU + 1) * 4 + 4    // tau, maskw + candw, tptr (+pad)
+           + (size_t)TCAP * 12;                                            // cached targets
+}
 
 // Prepare (U', I', uadd, iadd, cdot) for a score kind.  Returns DR_OK / error.
 static int prepare_operands(const float* U, const float* U2, int64_t Nu, const float* I, const float* I2,
