@@ -1,0 +1,134 @@
+"""Evaluation Metrics for sequential recommendation -- drop-in for utils/evaluation/SeqRecMetrics.py.
+
+evaluate1 (AttRec / PRME two-distance score, SeqRecMetrics.py:91-177), evaluate_caser (GEMM + item bias,
+:179-248) and evaluate (per-user predict, :250-295) keep their protocol (getUserParam / getItemParam /
+predict, test_users, neg_items, test_data, num_item, alpha) and printed lines; scoring, masking and ranking
+run in one dr_score_topk_f32 launch.  Each returns the dict of means it prints.
+
+Deviation kept explicit: the reference indexes `results[u, j]` with the user ID while `results` holds one
+row per entry of test_users (SeqRecMetrics.py:107,141) -- only consistent when test_users == range(n).
+Here row r of the user parameters belongs to test_users[r].
+"""
+import math
+
+import numpy as np
+import torch
+
+from ._ranks import masked_items, pack_csr, seq_user_metrics, split_ranks
+
+
+def precision_recall_ndcg_at_k(k, rankedlist, test_matrix):
+    """SeqRecMetrics.py:23-43 (first value is the hit COUNT)."""
+    idcg_k = 0
+    dcg_k = 0
+    n_k = k if len(test_matrix) > k else len(test_matrix)
+    for i in range(n_k):
+        idcg_k += 1 / math.log(i + 2, 2)
+    s2 = set(test_matrix)
+    hits = [(idx, val) for idx, val in enumerate(rankedlist) if val in s2]
+    count = len(hits)
+    for c in range(count):
+        dcg_k += 1 / math.log(hits[c][0] + 2, 2)
+    return count, float(count / len(test_matrix)), float(dcg_k / idcg_k)
+
+
+def map_mrr_ndcg(rankedlist, test_matrix):
+    """SeqRecMetrics.py:47-81 (first value is AUC)."""
+    ap = 0
+    dcg = 0
+    idcg = 0
+    mrr = 0
+    for i in range(len(test_matrix)):
+        idcg += 1 / math.log(i + 2, 2)
+    s2 = set(test_matrix)
+    hits = [(idx, val) for idx, val in enumerate(rankedlist) if val in s2]
+    count = len(hits)
+    for c in range(count):
+        ap += (c + 1) / (hits[c][0] + 1)
+        dcg += 1 / math.log(hits[c][0] + 2, 2)
+    if count != 0:
+        mrr = 1 / (hits[0][0] + 1)
+    max = len(rankedlist) - 1
+    count_test = max - hits[0][0] if count != 0 else 0
+    auc = 1.0 * count_test / max
+    return auc, mrr, float(dcg / idcg)
+
+
+def _t(a, dev):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=dev, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
+
+
+def _rank(self, users, U, I, kind, U2=None, I2=None, alpha=0.0, bias=None, scores=None):
+    from ... import kernels as Kn
+    dev = torch.device(getattr(self, "device", "cuda:0"))
+    num_item = int(self.num_item)
+    tgt = [np.unique(np.asarray(self.test_data[u], np.int64)) for u in users]
+    masked = [masked_items(self.neg_items[u], num_item) for u in users]
+    tp, ti = pack_csr(masked, dev)
+    gp, gi = pack_csr(tgt, dev)
+    if scores is not None:
+        _, _, rank = Kn.topk_rank(scores, 50, train=(tp, ti), targets=(gp, gi))
+    else:
+        _, _, rank = Kn.score_topk(_t(U, dev), _t(I, dev), 50, score_kind=kind,
+                                   U2=None if U2 is None else _t(U2, dev), I2=None if I2 is None else _t(I2, dev),
+                                   alpha=alpha, item_bias=None if bias is None else _t(bias, dev).reshape(-1),
+                                   train=(tp, ti), targets=(gp, gi))
+    return split_ranks(rank, tgt), [num_item - len(m) for m in masked]
+
+
+def _report(self, users, ranks, n_cand, with_auc):
+    hr_at_50, mrr, auc = [], [], []
+    for r, u in enumerate(users):
+        h, m, a = seq_user_metrics(ranks[r], len(self.test_data[u]), n_cand[r], 50)
+        hr_at_50.append(h)
+        mrr.append(m)
+        auc.append(a)
+    print(np.sum(hr_at_50))
+    print("------------------------")
+    res = {"HR@50": float(np.mean(hr_at_50)), "MRR": float(np.mean(mrr))}
+    print("HR@50:" + str(np.mean(hr_at_50)))
+    print("MRR:" + str(np.mean(mrr)))
+    if with_auc:
+        res["AUC"] = float(np.mean(auc))
+        print("AUC:" + str(np.mean(auc)))
+    return res
+
+
+def evaluate1(self):
+    """SeqRecMetrics.py:91-177: results = -alpha*||p_u - X_i||^2 - (1-alpha)*||s_u - Q_i||^2."""
+    from ... import kernels as Kn
+    users = [u for u in self.test_users]
+    user_factors, seq_factors, _, _ = self.getUserParam(self.test_users)
+    item_factors_1, item_factors_2, _ = self.getItemParam(np.expand_dims(np.arange(self.num_item), axis=1))
+    print(np.shape(user_factors))
+    print(np.shape(item_factors_1))
+    ranks, n_cand = _rank(self, users, user_factors, item_factors_1, Kn.SCORE_TWO_DIST, seq_factors, item_factors_2,
+                          float(self.alpha))
+    return _report(self, users, ranks, n_cand, True)
+
+
+def evaluate_caser(self):
+    """SeqRecMetrics.py:179-248: results = user_factors @ item_factors.T + bias_item."""
+    from ... import kernels as Kn
+    users = [u for u in self.test_users]
+    user_factors = self.getUserParam(self.test_users)
+    item_factors, bias_item = self.getItemParam(np.expand_dims(np.arange(self.num_item), axis=1))
+    ranks, n_cand = _rank(self, users, user_factors, item_factors, Kn.SCORE_DOT, bias=bias_item)
+    return _report(self, users, ranks, n_cand, False)
+
+
+def evaluate(self):
+    """SeqRecMetrics.py:250-295: per-user model.predict over the candidates."""
+    users = [u for u in self.test_users]
+    dev = torch.device(getattr(self, "device", "cuda:0"))
+    num_item = int(self.num_item) if hasattr(self, "num_item") else 1 + max(max(self.neg_items[u]) for u in users)
+    self.num_item = num_item
+    scores = torch.empty((len(users), num_item), dtype=torch.float32, device=dev)
+    all_items = list(range(num_item))
+    for r, u in enumerate(users):
+        s = self.predict([u] * num_item, all_items)
+        scores[r] = torch.as_tensor(np.asarray(s, np.float32).reshape(-1), device=dev)
+    ranks, n_cand = _rank(self, users, None, None, 0, scores=scores)
+    return _report(self, users, ranks, n_cand, False)
