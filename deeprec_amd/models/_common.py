@@ -1,0 +1,226 @@
+"""Host-side plumbing shared by the model classes: device placement, the lazy `neg_items` mapping of the
+evaluator protocol, reference-compatible negative sampling, TF-semantics optimizer state, and a minimal
+autograd bridge (embedding lookups whose backward is the deterministic HIP scatter-add path).
+
+PyTorch is used for device memory, autograd bookkeeping and the small dense layers (rocBLAS / MIOpen
+GEMMs and convolutions); every embedding lookup, duplicate-summing backward, optimizer application, fused
+step and full-catalog evaluation goes through the C ABI (deeprec_amd.kernels).
+"""
+import numpy as np
+import torch
+
+from .. import kernels as K
+
+
+def device_of(device=None):
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("deeprec_amd models need an MI355X: torch.cuda.is_available() is False and there is "
+                               "no CPU fallback")
+        device = "cuda:0"
+    return torch.device(device)
+
+
+def shift_sess(sess, num_user, num_item):
+    """D2: the reference drivers call Model(n_user, n_item) for classes whose first parameter is `sess`
+    (test_item_ranking.py:53-69).  Accept both call shapes."""
+    if num_item is None:
+        return None, sess, num_user
+    return sess, num_user, num_item
+
+
+class NegItems:
+    """model.neg_items: u -> ascending list of the items the user has NOT interacted with
+    (bprmf.py:175-181).  Materialised per request from the train CSR instead of as U x I Python sets."""
+
+    def __init__(self, csr, num_item, first_item=0):
+        self.csr, self.num_item, self.first = csr.tocsr(), int(num_item), int(first_item)
+        self.csr.sort_indices()
+
+    def train_items(self, u):
+        return self.csr.indices[self.csr.indptr[u]:self.csr.indptr[u + 1]]
+
+    def count(self, u):
+        t = self.train_items(u)
+        return self.num_item - self.first - int(np.count_nonzero(t >= self.first))
+
+    def __getitem__(self, u):
+        m = np.ones(self.num_item, bool)
+        m[:self.first] = False
+        m[self.train_items(u)] = False
+        return np.flatnonzero(m)
+
+    def __len__(self):
+        return self.csr.shape[0]
+
+    def __bool__(self):
+        return True
+
+    def keys(self):
+        return range(self.csr.shape[0])
+
+    def nth(self, u, s):
+        """neg_items[u][s] without materialising the list: the s-th item of the complement."""
+        t = self.train_items(u)
+        t = t[t >= self.first] - self.first
+        # complement rank: item x has rank x - (#train items < x); find smallest x with rank == s, x not in t
+        lo, hi = 0, len(t)
+        while lo < hi:                       # largest prefix of t lying before the answer
+            mid = (lo + hi) // 2
+            if t[mid] - mid <= s:
+                lo = mid + 1
+            else:
+                hi = mid
+        return int(s + lo + self.first)
+
+
+def sample_uniform_negatives(users, neg, n_per_user=1):
+    """The reference's per-positive draw (bprmf.py:130-133, cml.py:108-111): for every user in order,
+    s = np.random.randint(len(neg_items[u])); item = neg_items[u][s].  Same RNG stream, no list building."""
+    out = np.empty((len(users), n_per_user), np.int32)
+    for r, u in enumerate(users):
+        c = neg.count(u)
+        for j in range(n_per_user):
+            out[r, j] = neg.nth(u, np.random.randint(c))
+    return out
+
+
+def to_dev(a, dtype, device):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizer state with TensorFlow semantics ([TF-ext]; hyper-parameters cited in the model files)
+# ----------------------------------------------------------------------------------------------
+class TFOptimizer:
+    """kind: 'adam' (TF1 eps 1e-8 / Keras 1e-7), 'adagrad' (initial accumulator 0.1), 'rmsprop', 'sgd'."""
+    KIND = {"sgd": K.OPT_SGD, "adam": K.OPT_ADAM, "adagrad": K.OPT_ADAGRAD, "rmsprop": K.OPT_RMSPROP}
+    NSLOTS = {"sgd": 0, "adam": 2, "adagrad": 1, "rmsprop": 2}
+
+    def __init__(self, kind, learning_rate, eps=None, beta1=0.9, beta2=0.999, initial_accumulator_value=0.1,
+                 rho=0.9, momentum=0.0):
+        self.kind, self.lr = kind, float(learning_rate)
+        self.eps = float(eps if eps is not None else (1e-8 if kind == "adam" else 1e-10))
+        self.beta1, self.beta2, self.acc0, self.rho, self.momentum = beta1, beta2, initial_accumulator_value, rho, momentum
+        self.step_count = 0
+        self._b1p = np.float32(1)
+        self._b2p = np.float32(1)
+        self.slots = {}
+
+    def slots_for(self, t):
+        key = t.data_ptr()
+        if key not in self.slots:
+            n = self.NSLOTS[self.kind]
+            if self.kind == "adagrad":
+                s = [torch.full_like(t, self.acc0)]
+            elif self.kind == "rmsprop":
+                s = [torch.ones_like(t), torch.zeros_like(t)]      # [TF-ext] RMSProp ms starts at 1, mom at 0
+            else:
+                s = [torch.zeros_like(t) for _ in range(n)]
+            self.slots[key] = (s + [None, None])[:2]
+        return self.slots[key]
+
+    def begin_step(self):
+        self.step_count += 1
+        self._b1p = np.float32(self._b1p * np.float32(self.beta1))
+        self._b2p = np.float32(self._b2p * np.float32(self.beta2))
+
+    def params(self, reg, reg_mode):
+        alpha = 0.0
+        if self.kind == "adam":
+            alpha = float(np.float32(self.lr) * np.sqrt(np.float32(1) - self._b2p) / (np.float32(1) - self._b1p))
+        return K.opt_params(self.KIND[self.kind], lr=self.lr, alpha=alpha, beta1=self.beta1, beta2=self.beta2,
+                            eps=self.eps, rho=self.rho, momentum=self.momentum, reg=float(reg), reg_mode=reg_mode)
+
+    def apply_dense(self, w, grad, reg=0.0):
+        """Whole-tensor application; reg > 0 adds reg*w (tf l2_regularizer / l2_loss terms)."""
+        s0, s1 = self.slots_for(w)
+        K.dense_update(w, s0, s1, grad, self.params(reg, K.REG_DENSE if reg else K.REG_NONE))
+
+    def apply_table(self, table, reg, reg_mode):
+        """Apply the recorded lookups' gradients of one embedding table."""
+        s0, s1 = self.slots_for(table.w)
+        pend, table.pending = table.pending, []
+        if reg_mode == K.REG_DENSE:
+            G = table.dense_grad()
+            for ids, rows in pend:
+                K.scatter_add(G, ids, rows)
+            K.dense_update(table.w, s0, s1, G, self.params(reg, K.REG_DENSE))
+            return
+        if not pend:
+            return
+        ids = torch.cat([p[0] for p in pend]) if len(pend) > 1 else pend[0][0]
+        rows = torch.cat([p[1] for p in pend]) if len(pend) > 1 else pend[0][1]
+        K.sparse_row_update(table.w, s0, s1, ids.contiguous(), rows.contiguous(), self.params(reg, reg_mode))
+
+
+class Table:
+    """An embedding table [rows, k] (or a [rows] vector) living in HBM."""
+
+    def __init__(self, w):
+        self.w = w.contiguous()
+        self.pending = []
+        self._g = None
+        self._hook = torch.zeros((), device=w.device, requires_grad=True)
+
+    @property
+    def k(self):
+        return 1 if self.w.dim() == 1 else self.w.shape[1]
+
+    def dense_grad(self):
+        if self._g is None:
+            self._g = torch.empty_like(self.w)
+        self._g.zero_()
+        return self._g
+
+    def lookup(self, ids):
+        """tf.nn.embedding_lookup with the HIP gather; differentiable (backward is recorded for apply_table)."""
+        return _Lookup.apply(self._hook, self, ids)
+
+
+class _Lookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hook, table, ids):
+        ctx.table, ctx.ids = table, ids
+        return K.gather(table.w, ids)
+
+    @staticmethod
+    def backward(ctx, gout):
+        t = ctx.table
+        ids = ctx.ids.reshape(-1)
+        if ids.dtype != torch.int32:
+            ids = ids.to(torch.int32)
+        t.pending.append((ids.contiguous(), gout.reshape(ids.numel(), -1).contiguous() if t.w.dim() == 2
+                          else gout.reshape(-1).contiguous()))
+        return None, None, None
+
+
+class _BiInteraction(torch.autograd.Function):
+    """NFM bi-interaction pooling fused with its lookup (nfm.py:54-61)."""
+
+    @staticmethod
+    def forward(ctx, hook, table, feats):
+        fm, s = K.bi_interaction_fwd(table.w, feats)
+        ctx.table, ctx.feats, ctx.s = table, feats, s
+        return fm
+
+    @staticmethod
+    def backward(ctx, gfm):
+        t = ctx.table
+        gv = K.bi_interaction_bwd(t.w, ctx.feats, gfm.contiguous(), ctx.s)
+        t.pending.append((ctx.feats.reshape(-1), gv.reshape(-1, gv.shape[-1])))
+        return None, None, None
+
+
+def bi_interaction(table, feats):
+    return _BiInteraction.apply(table._hook, table, feats)
+
+
+def normal_(shape, std, device, seed=None):
+    """Initial values ~ N(0, std^2).  TensorFlow's RNG stream cannot be reproduced: parity tests
+    pass tables in explicitly; here the counter-based generator of the library is used."""
+    w = torch.empty(shape, dtype=torch.float32, device=device)
+    if seed is None:
+        seed = int(np.random.randint(0, 2 ** 31 - 1))
+    K.init_normal_(w, seed, std)
+    return w

@@ -75,6 +75,8 @@ def rank_targets(model, users, K=10):
         idx, _, rank = Kn.score_topk(ops["U"], ops["I"], K, score_kind=ops.get("kind", Kn.SCORE_DOT),
                                      U2=ops.get("U2"), I2=ops.get("I2"), alpha=ops.get("alpha", 0.0),
                                      item_bias=ops.get("item_bias"), train=(tp, ti), targets=(gp, gi))
+    elif hasattr(model, "eval_scores"):
+        idx, _, rank = Kn.topk_rank(model.eval_scores(users), K, train=(tp, ti), targets=(gp, gi))
     else:
         # duck-typed models: predict() per user over the whole catalog, selection on the GPU
         scores = torch.empty((len(users), num_item), dtype=torch.float32, device=dev)

@@ -1,0 +1,226 @@
+"""GPU tests of the host-side mirror: model classes and evaluate(model) protocols, through the C ABI."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import c_oracle as co
+from oracle import ref_ops as ro
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+class Stub:
+    pass
+
+
+def quiet(fn, *a):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a)
+
+
+def test_ranking_evaluate_matches_reference_goldens(dev):
+    """RankingMetrics.evaluate(model) on stub models vs the means the REFERENCE's evaluate printed for the same
+    inputs: (a) duck-typed predict path, (b) fused bilinear path (eval_operands)."""
+    from deeprec_amd import kernels as K
+    from deeprec_amd.utils.evaluation.RankingMetrics import evaluate
+    for case in load("ranking_evaluate.json"):
+        P, Q = np.array(case["P"], np.float32), np.array(case["Q"], np.float32)
+        ni = Q.shape[0]
+        test = {int(u): np.array(v) for u, v in case["test"].items()}
+        m = Stub()
+        m.device = dev
+        m.num_item = ni
+        m.test_users = set(u for u in test if len(test[u]) > 0)
+        m.neg_items = {u: [i for i in range(ni) if i not in set(t)] for u, t in enumerate(case["train"])}
+        m.test_data = test
+        m.predict = lambda us, its: (P[np.array(us)] * Q[np.array(its)]).sum(1).astype(np.float32)
+        res = quiet(evaluate, m)
+        for k, v in case["printed"].items():
+            assert abs(res[k] - v) <= 1e-12, (k, res[k], v)
+        exact = np.array_equal(P * 2, np.round(P * 2))          # quantised case: every score is exact in fp32
+        Pd, Qd = torch.from_numpy(P).to(dev), torch.from_numpy(Q).to(dev)
+        m.eval_operands = lambda users: {"U": Pd[torch.as_tensor(list(users), device=dev)].contiguous(), "I": Qd,
+                                         "kind": K.SCORE_DOT}
+        res2 = quiet(evaluate, m)
+        for k, v in case["printed"].items():
+            assert abs(res2[k] - v) <= (1e-12 if exact else 2e-2), (k, res2[k], v)
+
+
+def test_seq_evaluators_match_reference_goldens(dev):
+    from deeprec_amd.utils.evaluation import SeqRecMetrics as SM
+    for case in load("seq_evaluate.json"):
+        P, S, X, Q = (np.array(case[k], np.float32) for k in ("P", "S", "X", "Q"))
+        bias = np.array(case["bias"], np.float32)
+        test = {int(u): np.array(v) for u, v in case["test"].items()}
+        ni = Q.shape[0]
+        exact = np.array_equal(S * 2, np.round(S * 2))
+        m = Stub()
+        m.device, m.num_item, m.alpha = dev, ni, case["alpha"]
+        m.test_users = [u for u in range(P.shape[0])]
+        m.neg_items = {u: [i for i in range(ni) if i not in set(t)] for u, t in enumerate(case["train"])}
+        m.test_data = test
+        users = [u for u in m.test_users if len(test[u]) > 0]
+        m.test_users = users
+        m.getUserParam = lambda us: (P[us], S[us], P[us], None)
+        m.getItemParam = lambda items: (X, Q, bias)
+        r1 = quiet(SM.evaluate1, m)
+        m.getUserParam = lambda us: P[us]
+        m.getItemParam = lambda items: (Q, bias)
+        r2 = quiet(SM.evaluate_caser, m)
+        m.predict = lambda us, its: (P[np.array(us)] * Q[np.array(its)]).sum(1).astype(np.float32)
+        r3 = quiet(SM.evaluate, m)
+        # the two-distance score is computed in the expanded (GEMM) form: not bit-identical to numpy's direct
+        # differences, so near-ties may reorder -> exact only for the predict path
+        for got, key, tol in ((r1, "evaluate1", 5e-2), (r2, "evaluate_caser", 5e-2), (r3, "evaluate", 1e-12)):
+            for k, v in case[key].items():
+                assert abs(got[k] - v) <= tol * max(1.0, abs(v)), (key, k, got[k], v)
+
+
+def _toy_data(rng, nu, ni, per_user=12):
+    rows, cols = [], []
+    test = {}
+    for u in range(nu):
+        items = rng.permutation(ni)[:per_user + 3]
+        rows += [u] * per_user
+        cols += items[:per_user].tolist()
+        test[u] = np.sort(items[per_user:])
+    train = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(nu, ni)).todok()
+    return train, test
+
+
+def test_bprmf_class_matches_oracle(dev):
+    """BPRMF drop-in: two epochs on a toy log with the tables passed in; host sampling replayed through the
+    oracle step by step (dense L2 + Keras Adam, the reference semantics)."""
+    from deeprec_amd.models.item_ranking.bprmf import BPRMF
+    from deeprec_amd.models import _common
+    rng = np.random.default_rng(0)
+    nu, ni, k, B = 40, 60, 30, 64
+    train, test = _toy_data(rng, nu, ni)
+    P0 = (rng.standard_normal((nu, k)) * 0.01).astype(np.float32)
+    Q0 = (rng.standard_normal((ni, k)) * 0.01).astype(np.float32)
+    model = quiet(BPRMF, nu, ni, 0.001, 0.1, 2, B)
+    model.build_network(num_factor=k, P=P0, Q=Q0)
+    quiet(model.prepare_data, train, test)
+    assert model.total_batch == 480 // B
+    # neg_items protocol object == the reference's list(all_items - seen)
+    csr = train.tocsr()
+    for u in (0, 7, 39):
+        assert list(model.neg_items[u]) == sorted(set(range(ni)) - set(csr.getrow(u).nonzero()[1]))
+    P, Q = P0.copy(), Q0.copy()
+    sP, sQ = [np.zeros_like(P), np.zeros_like(P)], [np.zeros_like(Q), np.zeros_like(Q)]
+    step = 0
+    for epoch in range(2):
+        np.random.seed(100 + epoch)
+        model.train()
+        np.random.seed(100 + epoch)                       # replay the host-side sampling for the oracle
+        idxs = np.random.permutation(model.num_training)
+        ur, ir = model.user[idxs], model.item[idxs]
+        jr = _common.sample_uniform_negatives(ur, model.neg_items)[:, 0]
+        for b in range(model.total_batch):
+            step += 1
+            s = slice(b * B, (b + 1) * B)
+            hp = dict(alpha=float(ro.adam_alpha(0.001, 0.9, 0.999, step)), beta1=0.9, beta2=0.999, eps=1e-7)
+            P, Q, sP, sQ, _, _ = ro.pairwise_step(P, Q, sP, sQ, ur[s], ir[s], jr[s], ro.OPT_ADAM, hp, 0.1, ro.REG_DENSE)
+    np.testing.assert_allclose(model.P.cpu().numpy(), P, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(model.Q.cpu().numpy(), Q, rtol=1e-4, atol=1e-6)
+    # predict == canonical fmaf chain; evaluate == oracle evaluator on the model's own tables
+    us, its = rng.integers(0, nu, 50), rng.integers(0, ni, 50)
+    Pn, Qn = model.P.cpu().numpy(), model.Q.cpu().numpy()
+    assert np.array_equal(model.predict(us, its), co.pair_dot(Pn, Qn, us, its))
+    res = quiet(model.test)
+    ref, top10 = ro.evaluate_ranking(lambda u_, i_: co.pair_dot(Pn, Qn, u_, i_), list(model.test_users),
+                                     {u: model.neg_items[u] for u in range(nu)}, test)
+    for kk in ref:
+        assert abs(res[kk] - ref[kk]) <= 1e-12, kk
+    for u in list(model.test_users)[:10]:
+        assert model.pred_ratings_10[u] == [int(x) for x in top10[u]]
+
+
+def test_d1_intended_id_order(dev):
+    """the reference feeds (item, user, neg) into a (user, item, neg) model (bprmf.py:117).  The build
+    uses the intended order: user ids index P, item ids index Q -- ids >= num_user are valid ITEM ids."""
+    from deeprec_amd.models.item_ranking.bprmf import BPRMF
+    nu, ni = 5, 50
+    model = quiet(BPRMF, nu, ni, 0.001, 0.1, 1, 4)
+    model.build_network(num_factor=8)
+    P0, Q0 = model.P.clone(), model.Q.clone()
+    u = torch.tensor([0, 1, 2, 3], dtype=torch.int32, device=dev)
+    i = torch.tensor([40, 41, 42, 49], dtype=torch.int32, device=dev)      # >= num_user: fine for Q
+    j = torch.tensor([10, 11, 12, 13], dtype=torch.int32, device=dev)
+    model.train_op(u, i, j)
+    assert not torch.equal(model.Q[40], Q0[40]) and not torch.equal(model.P[0], P0[0])
+
+
+def test_gmf_cml_mf_classes_smoke_and_oracle(dev):
+    from deeprec_amd.models.item_ranking.cml import CML, CMLwarp
+    from deeprec_amd.models.item_ranking.gmf import GMF
+    from deeprec_amd.models.rating_prediction.mf import MF
+    rng = np.random.default_rng(1)
+    nu, ni = 30, 45
+    train, test = _toy_data(rng, nu, ni, 10)
+    # GMF: both call shapes (D2), one train_op vs oracle, evaluate runs
+    g = quiet(GMF, nu, ni)
+    g2 = quiet(GMF, None, nu, ni, 0.5, 0.01, 1, 32)
+    assert (g.num_user, g.num_item) == (g2.num_user, g2.num_item) == (nu, ni)
+    P0 = rng.standard_normal((nu, 10)).astype(np.float32)
+    Q0 = rng.standard_normal((ni, 10)).astype(np.float32)
+    g2.build_network(num_factor=10, num_neg_sample=3, P=P0, Q=Q0)
+    quiet(g2.prepare_data, train, test)
+    u = rng.integers(0, nu, 32).astype(np.int32)
+    i = rng.integers(0, ni, 32).astype(np.int32)
+    y = rng.integers(0, 2, 32).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    g2.train_op(t(u), t(i), t(y))
+    ref = ro.pointwise_step(P0, Q0, [np.full_like(P0, 0.1)], [np.full_like(Q0, 0.1)], u, i, y, "bce", ro.OPT_ADAGRAD,
+                            dict(lr=0.5), 0.01, ro.REG_DENSE)
+    np.testing.assert_allclose(g2.P.cpu().numpy(), ref[0], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(g2.Q.cpu().numpy(), ref[1], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(g2.predict(u, i), ro.bce_forward(ref[0], ref[1], u, i, y)[2], rtol=1e-5, atol=1e-6)
+    random_state = __import__("random").getstate()
+    quiet(g2.train)
+    __import__("random").setstate(random_state)
+    res = quiet(g2.test)
+    assert set(res) >= {"ndcg@10", "map"} and 0 <= res["ndcg@10"] <= 1
+    # CML / CMLwarp: one epoch + evaluate; rows stay inside the unit ball (cml.py:80-81)
+    for cls in (CML, CMLwarp):
+        c = quiet(cls, None, nu, ni, 0.1, 0.1, 1, 50)
+        c.build_network(num_factor=20)
+        quiet(c.prepare_data, train, test)
+        quiet(c.train)
+        assert float((c.P * c.P).sum(1).max()) <= 1 + 1e-5 and float((c.Q * c.Q).sum(1).max()) <= 1 + 1e-5
+        res = quiet(c.test)
+        Pn, Qn = c.P.cpu().numpy(), c.Q.cpu().numpy()
+        ref, _ = ro.evaluate_ranking(lambda u_, i_: co.score_matrix(Pn, Qn, 1)[np.array(u_), np.array(i_)],
+                                     list(c.test_users), {u_: c.neg_items[u_] for u_ in range(nu)}, test)
+        for kk in ref:
+            assert abs(res[kk] - ref[kk]) <= 1e-12, kk
+        np.testing.assert_allclose(c.predict(u, i), -((Pn[u] - Qn[i]) ** 2).sum(1), rtol=1e-5, atol=1e-6)
+    # MF: ratings; the fit on the training pairs improves, test() == RMSE/MAE of predict() (mf.py:80-88)
+    rt = sp.random(nu, ni, 0.3, random_state=3, format="csr")
+    rt.data = np.ceil(rt.data * 5)
+    m = quiet(MF, None, nu, ni, 0.01, 0.01, 3, 16)
+    m.build_network(num_factor=8)
+    m.user, m.item, m.rating = rt.tocoo().row, rt.tocoo().col, rt.tocoo().data
+    m.mu = float(np.mean(m.rating))
+    before = quiet(m.test, rt.todok())
+    for _ in range(20):
+        quiet(m.train, rt)
+    after = quiet(m.test, rt.todok())
+    assert after["RMSE"] < before["RMSE"]
+    d = rt.todok()
+    keys = list(d.keys())
+    pr = m.predict([k_[0] for k_ in keys], [k_[1] for k_ in keys]).astype(np.float64)
+    yy = np.array([d[k_] for k_ in keys])
+    assert abs(after["RMSE"] - np.sqrt(np.mean((yy - pr) ** 2))) < 1e-9 and abs(after["MAE"] - np.mean(np.abs(yy - pr))) < 1e-9
