@@ -1,0 +1,150 @@
+"""Self-attentive sequential recommendation -- drop-in for models/seq_rec/AttRec.py (class AttRec).
+
+Graph (AttRec.py:41-112,132-232): tables P,V [U,d], Q,X,A [I,d] (truncated N, 0.001), W [I,2d], b [I];
+Q[item_seq] + sinusoidal timing -> shared ReLU projection for query and key (no bias, Xavier, L2) ->
+softmax(q k^T / sqrt(d)) with the diagonal zeroed AFTER the softmax -> weights @ Q[item_seq] -> mean over L;
+score = 0.2*||X_i - p_u||^2 + 0.8*||out - Q_i||^2; hinge(target - negative + 0.5) + 0.001*(l2 P,V,X,Q) + kernel
+reg; Adagrad(0.05, initial accumulator 0.05).  test() -> SeqRecMetrics.evaluate1 (fused two-distance scoring).
+"""
+import math
+
+import numpy as np
+import torch
+
+from ... import kernels as K
+from ...utils.evaluation.SeqRecMetrics import evaluate1
+from .._common import TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from ._seq_common import SeqBase
+
+
+def timing_signal(length, channels, device, min_timescale=1.0, max_timescale=1.0e4):
+    """AttRec.py:468-510 (tensor2tensor's add_timing_signal_1d), returned as [1, length, channels]."""
+    position = torch.arange(length, dtype=torch.float32, device=device)
+    num_timescales = channels // 2
+    inc = math.log(float(max_timescale) / float(min_timescale)) / (float(num_timescales) - 1)
+    inv = min_timescale * torch.exp(torch.arange(num_timescales, dtype=torch.float32, device=device) * -inc)
+    scaled = position[:, None] * inv[None]
+    signal = torch.cat((torch.sin(scaled), torch.cos(scaled)), 1)
+    if channels % 2:
+        signal = torch.nn.functional.pad(signal, (0, 1))
+    return signal.reshape(1, length, channels)
+
+
+class AttRec(SeqBase):
+    def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.05, reg_rate=1e-2, epoch=5000, batch_size=1000,
+                 show_time=False, T=1, display_step=1000, verbose=False, device=None):
+        self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
+        self.learning_rate = learning_rate
+        self.epochs = epoch
+        self.batch_size = batch_size
+        self.reg_rate = reg_rate
+        self.show_time = show_time
+        self.verbose = verbose
+        self.T = T
+        self.display_step = display_step
+        self.device = device_of(device)
+        self.neg_items = dict()
+        self.alpha = 0.2
+        print("AttSeqRec.")
+
+    def build_network(self, L, num_T, num_factor=150, num_neg=1, init=None):
+        self.L, self.num_T, self.num_factor, self.num_neg = L, num_T, num_factor, num_neg
+        dev, d = self.device, num_factor
+        init = init or {}
+
+        def tab(n, rows, k, std):
+            if n in init:
+                return Table(to_dev(init[n], torch.float32, dev))
+            w = normal_((rows, k) if k else (rows,), std, dev)
+            return Table(w.clamp_(-2 * std, 2 * std) if n in "PVQXA" else w)    # truncated normal: |x| <= 2 sigma
+        self.P, self.V = tab("P", self.num_user, d, 0.001), tab("V", self.num_user, d, 0.001)
+        self.Q, self.X, self.A = tab("Q", self.num_item, d, 0.001), tab("X", self.num_item, d, 0.001), tab("A", self.num_item, d, 0.001)
+        self.W, self.b = tab("W", self.num_item, 2 * d, 0.01), tab("b", self.num_item, 0, 0.01)
+        if "linear_project" in init:
+            Wp = to_dev(init["linear_project"], torch.float32, dev)
+        else:                                                           # xavier_initializer: U(+-sqrt(6/(fan_in+fan_out)))
+            lim = math.sqrt(6.0 / (d + d))
+            Wp = (torch.rand((d, d), device=dev) * 2 - 1) * lim
+        self.linear_project = Wp.requires_grad_(True)
+        self.optimizer = TFOptimizer("adagrad", self.learning_rate, initial_accumulator_value=0.05)
+        return self
+
+    def _seq_out(self, item_seq):
+        """AttRec.py:142-186 -> (out [B,d], weights [B,L,L])."""
+        v = self.Q.lookup(item_seq)                                     # [B,L,d]
+        x = v + timing_signal(self.L, self.num_factor, self.device)
+        q = torch.relu(x @ self.linear_project)
+        logits = q @ q.transpose(1, 2) / np.sqrt(self.num_factor)
+        w = torch.softmax(logits, -1)
+        w = w * (1 - torch.eye(self.L, device=self.device))
+        return (w @ v).mean(1), w
+
+    def _distance(self, out, user_id, item_id):
+        """AttRec.py:190-232 -> [B, n]."""
+        w_items, w_items_2 = self.X.lookup(item_id), self.Q.lookup(item_id)
+        u = self.P.lookup(user_id)[:, None, :]
+        return self.alpha * ((w_items - u) ** 2).sum(2) + (1 - self.alpha) * ((out[:, None, :] - w_items_2) ** 2).sum(2)
+
+    def train_op(self, user_id, item_seq, item_id, neg_item_id):
+        self.linear_project.grad = None
+        out, _ = self._seq_out(item_seq)
+        target = self._distance(out, user_id, item_id)
+        negative = self._distance(out, user_id, neg_item_id)
+        loss = torch.clamp(target - negative + 0.5, min=0).sum()
+        loss.backward()
+        o = self.optimizer
+        o.begin_step()
+        with torch.no_grad():
+            for t in (self.P, self.V, self.X, self.Q):
+                o.apply_table(t, 0.001, K.REG_DENSE)
+            o.apply_dense(self.linear_project.data, self.linear_project.grad, self.reg_rate)
+        return loss.detach()
+
+    def prepare_data(self, train_data, test_data):
+        self._prepare(train_data, test_data)
+
+    def train(self, train_data):
+        self.test_sequences = train_data.test_sequences.sequences
+        self._train_epoch(self.num_neg * self.num_T)
+
+    def test(self, test_data):
+        self.test_users = [i for i in range(self.num_user)]
+        return evaluate1(self)
+
+    def execute(self, train_data, test_data):
+        self.prepare_data(train_data, test_data)
+        for epoch in range(self.epochs):
+            if self.verbose:
+                print("Epoch: %04d;" % (epoch))
+            self.train(train_data)
+            if (epoch) % self.T == 0 and epoch >= 5:
+                print("Epoch: %04d; " % (epoch), end='')
+                self.test(test_data)
+
+    def getUserParam(self, user_id):
+        """AttRec.py:116-119 -> (P_u, attention output of the user's test sequence, V_u, attention weights)."""
+        u = to_dev(np.asarray(user_id).reshape(-1), torch.int32, self.device)
+        seq = to_dev(self.test_sequences[np.asarray(user_id).reshape(-1), :], torch.int32, self.device)
+        with torch.no_grad():
+            out, w = self._seq_out(seq)
+            return K.gather(self.P.w, u), out.contiguous(), K.gather(self.V.w, u), w
+
+    def getItemParam(self, item_id):
+        """AttRec.py:121-123 -> (X rows, Q rows, b[item_id])."""
+        i = to_dev(np.asarray(item_id).reshape(-1), torch.int32, self.device)
+        return K.gather(self.X.w, i), K.gather(self.Q.w, i), K.gather(self.b.w, i)
+
+    def predict(self, user_id, item_id):
+        """AttRec.py:404-415: minus the test-graph distance."""
+        u = to_dev(np.asarray(user_id).reshape(-1), torch.int32, self.device)
+        seq = to_dev(self.test_sequences[np.asarray(user_id).reshape(-1), :], torch.int32, self.device)
+        it = to_dev(np.asarray(item_id).reshape(-1, 1), torch.int32, self.device)
+        with torch.no_grad():
+            out, _ = self._seq_out(seq)
+            return (-self._distance(out, u, it)).reshape(-1).cpu().numpy()
+
+    def save(self, path):
+        from safetensors.torch import save_file
+        d = {n: getattr(self, n).w for n in ("P", "V", "Q", "X", "A", "W", "b")}
+        d["linear_project"] = self.linear_project.data
+        save_file({k: v.detach().cpu().contiguous() for k, v in d.items()}, path)

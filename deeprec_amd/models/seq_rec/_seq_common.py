@@ -1,0 +1,63 @@
+"""Host logic shared by the sequential recommenders (AttRec.py:319-354,356-387,448-466; PRME.py:133-160;
+Caser.py:198-260): data preparation, negative sampling and the training loop skeleton."""
+import time
+
+import numpy as np
+import torch
+
+from .._common import NegItems, to_dev
+
+
+class SeqBase:
+    def _prepare(self, train_data, test_data):
+        """AttRec.py:319-354: sequences / targets / users from the DataSet, per-sample candidate pools
+        x[i] = all items (1..num_item-1; 0 is the pad) minus the sample's targets, test_data and neg_items."""
+        self.sequences = train_data.sequences.sequences
+        self.targets = train_data.sequences.targets
+        self.users = train_data.sequences.user_ids.reshape(-1, 1)
+        self.test_sequences = train_data.test_sequences.sequences
+        self.all_items = set(np.arange(self.num_item - 1) + 1)
+        self.test_data = dict()
+        test = test_data.tocsr()
+        for user in range(test.shape[0]):
+            self.test_data[user] = list(set(test.indices[test.indptr[user]:test.indptr[user + 1]]))
+        if not self.neg_items:
+            self.neg_items = NegItems(train_data.tocsr(), self.num_item, first_item=1)
+        print("Data Preparation Finish.")
+
+    def _sample_negatives(self, targets_random, n):
+        """AttRec.py:448-466 (_get_neg_items_sbpr): n draws per sample, uniformly from all_items - targets(sample),
+        via np.random.randint(len(pool)) -- same RNG stream, the pool is addressed without being built."""
+        num = self.num_item - 1
+        out = np.zeros((len(targets_random), n))
+        for r, tar in enumerate(targets_random):
+            t = np.unique(np.asarray(tar, np.int64))
+            t = t[(t >= 1) & (t <= num)] - 1                     # 0-based positions inside 1..num
+            m = num - len(t)
+            for j in range(n):
+                s = np.random.randint(m)
+                lo = 0
+                while lo < len(t) and t[lo] - lo <= s:
+                    lo += 1
+                out[r, j] = s + lo + 1
+        return out
+
+    def _train_epoch(self, n_neg):
+        """AttRec.py:356-387 / Caser / PRME: permutation, per-sample negatives, batches (remainder dropped)."""
+        self.num_training = len(self.sequences)
+        self.total_batch = int(self.num_training / self.batch_size)
+        idxs = np.random.permutation(self.num_training)
+        seq_r, tar_r, usr_r = self.sequences[idxs], self.targets[idxs], self.users[idxs][:, 0]
+        neg_r = self._sample_negatives(tar_r, n_neg)
+        dev = self.device
+        u_d = to_dev(usr_r, torch.int32, dev)
+        s_d = to_dev(seq_r, torch.int32, dev)
+        t_d = to_dev(tar_r, torch.int32, dev)
+        n_d = to_dev(neg_r, torch.int32, dev)
+        for i in range(self.total_batch):
+            start_time = time.time()
+            sl = slice(i * self.batch_size, (i + 1) * self.batch_size)
+            loss = self.train_op(u_d[sl].contiguous(), s_d[sl].contiguous(), t_d[sl].contiguous(), n_d[sl].contiguous())
+            if i % self.display_step == 0:
+                if self.verbose:
+                    print("Index: %04d; cost= %.9f" % (i + 1, float(loss.item())))

@@ -122,6 +122,11 @@ def evaluate_caser(self):
 def evaluate(self):
     """SeqRecMetrics.py:250-295: per-user model.predict over the candidates."""
     users = [u for u in self.test_users]
+    if hasattr(self, "seq_eval_operands"):           # models whose predict() is a two-distance / bilinear score
+        ops = self.seq_eval_operands(users)
+        ranks, n_cand = _rank(self, users, ops["U"], ops["I"], ops["kind"], ops.get("U2"), ops.get("I2"),
+                              ops.get("alpha", 0.0), ops.get("item_bias"))
+        return _report(self, users, ranks, n_cand, False)
     dev = torch.device(getattr(self, "device", "cuda:0"))
     num_item = int(self.num_item) if hasattr(self, "num_item") else 1 + max(max(self.neg_items[u]) for u in users)
     self.num_item = num_item

@@ -25,9 +25,9 @@ class Stub:
     pass
 
 
-def quiet(fn, *a):
+def quiet(fn, *a, **kw):
     with contextlib.redirect_stdout(io.StringIO()):
-        return fn(*a)
+        return fn(*a, **kw)
 
 
 def test_ranking_evaluate_matches_reference_goldens(dev):
@@ -224,3 +224,181 @@ def test_gmf_cml_mf_classes_smoke_and_oracle(dev):
     pr = m.predict([k_[0] for k_ in keys], [k_[1] for k_ in keys]).astype(np.float64)
     yy = np.array([d[k_] for k_ in keys])
     assert abs(after["RMSE"] - np.sqrt(np.mean((yy - pr) ** 2))) < 1e-9 and abs(after["MAE"] - np.mean(np.abs(yy - pr))) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd-bridged models: one training step against a plain torch-CPU fp32 restatement of the same graph
+# (dense autograd gradients + the oracle's TF optimizer arithmetic)
+# ---------------------------------------------------------------------------------------------------
+def _cpu_step(params, loss_fn, kind, hp, regs, slots):
+    """params: dict name -> np array; regs: name -> L2 coefficient (grad += reg * w); returns new params."""
+    leaves = {n: torch.tensor(v, dtype=torch.float32, requires_grad=True) for n, v in params.items()}
+    loss = loss_fn(leaves)
+    loss.backward()
+    out = {}
+    for n, t in leaves.items():
+        g = (t.grad if t.grad is not None else torch.zeros_like(t)).numpy()
+        g = (g + np.float32(regs.get(n, 0.0)) * params[n]).astype(np.float32)
+        w, _ = ro.opt_apply(kind, params[n], g, tuple(slots[n]), hp)
+        out[n] = w
+    return out, float(loss)
+
+
+def test_nfm_step_and_c3_shape(dev):
+    """Config 3 shape (M=5382, F=10, k=128, B=128; nfm.py:39-82) with the dropout mask passed in."""
+    from deeprec_amd.models.rating_prediction.nfm import NFM
+    rng = np.random.default_rng(0)
+    M, F, k, H, B = 5382, 10, 128, 128, 128
+    init = {"feature_embeddings": (rng.standard_normal((M, k)) * 0.01).astype(np.float32),
+            "feature_bias": (rng.standard_normal(M) * 0.01).astype(np.float32),
+            "bias": np.float32(0.1), "pred_weight": (rng.standard_normal((H, 1)) * 0.09).astype(np.float32),
+            "W1": rng.standard_normal((k, H)).astype(np.float32), "b1": rng.standard_normal(H).astype(np.float32)}
+    m = quiet(NFM, None, 957, 4082, 0.05, 0.01, 1, B)
+    m.build_network(M, k, H, init=init)
+    X = rng.integers(0, M, (B, F)).astype(np.int32)
+    X[:, 0] = X[0, 0]                                           # a feature shared by every row: duplicate-heavy
+    Y = rng.choice([-1.0, 1.0], (B, 1)).astype(np.float32)
+    mask = (rng.random((B, H)) < 0.8).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    loss = m.train_op(t(X), t(Y), t(mask))
+
+    def loss_fn(p):
+        v = p["feature_embeddings"][torch.from_numpy(X).long()]
+        s = v.sum(1)
+        fm = 0.5 * (s * s - (v * v).sum(1))
+        h = torch.relu(fm @ p["W1"] + p["b1"]) * torch.from_numpy(mask) / 0.8
+        pred = (h @ p["pred_weight"]).sum(1, keepdim=True) + p["feature_bias"][torch.from_numpy(X).long()].sum(1, keepdim=True) + p["bias"]
+        d = torch.from_numpy(Y) - pred
+        return 0.5 * (d * d).sum()
+    slots = {n: [np.full(np.shape(v), 0.1, np.float32)] for n, v in init.items()}
+    ref, lref = _cpu_step({n: np.asarray(v, np.float32) for n, v in init.items()}, loss_fn, ro.OPT_ADAGRAD,
+                          dict(lr=0.05), {"feature_embeddings": 0.01}, slots)
+    assert abs(float(loss) - lref) <= 1e-4 * abs(lref)
+    # feature_bias: true sparse gradient -> untouched rows keep their accumulator and value (nfm.py:74)
+    got_fb = m.feature_bias.w.cpu().numpy()
+    touched = np.unique(X)
+    np.testing.assert_allclose(got_fb[touched], ref["feature_bias"][touched], rtol=2e-4, atol=1e-6)
+    untouched = np.setdiff1d(np.arange(M), touched)
+    assert np.array_equal(got_fb[untouched], init["feature_bias"][untouched])
+    for n, got in (("feature_embeddings", m.feature_embeddings.w), ("W1", m.W1), ("b1", m.b1),
+                   ("pred_weight", m.pred_weight), ("bias", m.bias)):
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref[n], rtol=2e-4, atol=2e-6, err_msg=n)
+    # train()/test() plumbing on frappe-shaped lists
+    data = {"X": X.tolist(), "Y": Y.tolist()}
+    quiet(m.train, data)
+    r = quiet(m.test, data, t(np.ones((B, H), np.float32)))
+    assert np.isfinite(r["RMSE"])
+
+
+def test_neumf_step_eval_and_c2_shape(dev):
+    """NeuMF (neumf.py:61-131): one Adagrad step vs the CPU restatement; eval_scores == predict; evaluate runs."""
+    from deeprec_amd.models.item_ranking.neumf import NeuMF
+    rng = np.random.default_rng(2)
+    nu, ni, B = 50, 80, 256
+    train, test = _toy_data(rng, nu, ni, 10)
+    dims = [128, 128, 80, 40, 20, 10]
+    init = {"P": rng.standard_normal((nu, 10)), "Q": rng.standard_normal((ni, 10)),
+            "mlp_P": rng.standard_normal((nu, 64)) * 0.1, "mlp_Q": rng.standard_normal((ni, 64)) * 0.1}
+    for l in range(5):
+        init["W%d" % l] = rng.standard_normal((dims[l], dims[l + 1])) * 0.2
+        init["b%d" % l] = rng.standard_normal(dims[l + 1]) * 0.1
+    init = {n: v.astype(np.float32) for n, v in init.items()}
+    m = quiet(NeuMF, None, nu, ni, 0.5, 0.01, 1, B)
+    m.build_network(init=init, num_neg_sample=4)
+    quiet(m.prepare_data, train, test)
+    u = rng.integers(0, nu, B).astype(np.int32)
+    i = (rng.zipf(1.5, B) % ni).astype(np.int32)
+    y = rng.integers(0, 2, B).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    loss = m.train_op(t(u), t(i), t(y))
+
+    def loss_fn(p):
+        ul, il = torch.from_numpy(u).long(), torch.from_numpy(i).long()
+        x = torch.cat((p["mlp_Q"][il], p["mlp_P"][ul]), 1)
+        for l in range(5):
+            x = torch.relu(x @ p["W%d" % l] + p["b%d" % l])
+        z = torch.cat((p["P"][ul] * p["Q"][il], x), 1).sum(1)
+        pr = torch.sigmoid(z)
+        yy = torch.from_numpy(y)
+        return -(yy * torch.log(pr + 1e-10) + (1 - yy) * torch.log(1 - pr + 1e-10)).sum()
+    regs = {n: 0.01 for n in init if not n.startswith("b")}
+    slots = {n: [np.full(v.shape, 0.1, np.float32)] for n, v in init.items()}
+    ref, lref = _cpu_step(init, loss_fn, ro.OPT_ADAGRAD, dict(lr=0.5), regs, slots)
+    assert abs(float(loss) - lref) <= 1e-4 * abs(lref)
+    got = {"P": m.P.w, "Q": m.Q.w, "mlp_P": m.mlp_P.w, "mlp_Q": m.mlp_Q.w}
+    for l in range(5):
+        got["W%d" % l], got["b%d" % l] = m.kernels[l], m.biases[l]
+    for n in init:
+        np.testing.assert_allclose(got[n].detach().cpu().numpy(), ref[n], rtol=5e-4, atol=5e-6, err_msg=n)
+    # evaluator fast path == predict
+    users = [3, 7, 11]
+    sc = m.eval_scores(users).cpu().numpy()
+    for r, uu in enumerate(users):
+        np.testing.assert_allclose(sc[r], m.predict([uu] * ni, list(range(ni))), rtol=1e-5, atol=1e-6)
+    quiet(m.train)
+    res = quiet(m.test)
+    assert 0 <= res["ndcg@10"] <= 1
+
+
+def _seq_dataset(tmp_path, rng, nu=25, ni=40, L=3, T=2):
+    from deeprec_amd.utils.load_data.load_data_seq import DataSet
+    lines = []
+    for u in range(nu):
+        for it in rng.permutation(ni)[:int(rng.integers(L + T + 1, L + T + 6))]:
+            lines.append("%d %d 1\n" % (u + 1, it + 1))
+    p = tmp_path / "seq_train.txt"
+    p.write_text("".join(lines))
+    train = quiet(DataSet, str(p), ['user', 'item', 'rating'], " ", L, T, True)
+    tl = []
+    for u in range(nu):
+        tl.append("%d %d 1\n" % (u + 1, int(rng.integers(1, ni + 1))))
+    pt = tmp_path / "seq_test.txt"
+    pt.write_text("".join(tl))
+    test = quiet(DataSet, str(pt), ['user', 'item', 'rating'], " ", 1, 1, False, train.user_map, train.item_map,
+                 train.num_user, train.num_item)
+    return train, test
+
+
+def test_seq_models_train_and_evaluate(dev, tmp_path):
+    """AttRec / Caser / PRME drop-ins (testSeqRec.py:45-70 flow): prepare, one epoch, test(); the evaluators'
+    numbers equal the oracle ranking of the models' own predict() scores."""
+    from deeprec_amd.models.seq_rec.AttRec import AttRec
+    from deeprec_amd.models.seq_rec.Caser import Caser
+    from deeprec_amd.models.seq_rec.PRME import PRME
+    from deeprec_amd.utils.evaluation._ranks import seq_user_metrics
+    rng = np.random.default_rng(5)
+    for cls, L, kw in ((AttRec, 3, dict(num_factor=16)), (Caser, 3, dict(num_factor=16, n_h=4, n_v=2)),
+                       (PRME, 1, dict(num_factor=16))):
+        train, test = _seq_dataset(tmp_path, rng, L=L)
+        m = quiet(cls, None, train.num_user, train.num_item, 0.05 if cls is AttRec else 0.001, 0.01, 1, 20)
+        quiet(m.build_network, L, 2, **kw)
+        quiet(m.prepare_data, train, test)
+        np.random.seed(0)
+        quiet(m.train, train)
+        res = quiet(m.test, test)
+        assert np.isfinite(res["HR@50"]) and 0 <= res["MRR"] <= 1
+        # oracle ranking of predict() scores
+        ni = train.num_item
+        hr, mrr = [], []
+        for uu in m.test_users:
+            s = m.predict([uu] * ni, list(range(ni)))
+            cand = m.neg_items[uu]
+            masked = np.setdiff1d(np.arange(ni), cand)
+            _, _, ranks = ro.topk_and_ranks(s, masked, np.unique(m.test_data[uu]), 50)
+            h, mm, _ = seq_user_metrics(sorted(int(r) for r in ranks if r >= 0), len(m.test_data[uu]), len(cand), 50)
+            hr.append(h), mrr.append(mm)
+        # the fused kernels score in the expanded form: allow the rare near-tie reordering
+        assert abs(res["HR@50"] - np.mean(hr)) <= 0.05 and abs(res["MRR"] - np.mean(mrr)) <= 0.02, cls.__name__
+
+
+def test_nnmf_runs(dev):
+    from deeprec_amd.models.rating_prediction.nnmf import NNMF
+    rt = sp.random(30, 40, 0.3, random_state=3, format="csr")
+    rt.data = np.ceil(rt.data * 5)
+    m = quiet(NNMF, None, 30, 40, 0.001, 0.01, 1, 32)
+    quiet(m.build_network, 20, 4, 8)
+    m.user, m.item, m.rating = rt.tocoo().row, rt.tocoo().col, rt.tocoo().data
+    before = quiet(m.test, rt.todok())["RMSE"]
+    for _ in range(30):
+        quiet(m.train, rt)
+    assert quiet(m.test, rt.todok())["RMSE"] < before
