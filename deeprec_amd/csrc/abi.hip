@@ -28,7 +28,15 @@ __global__ __launch_bounds__(256) void init_normal_kernel(float* __restrict__ w,
 __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     __shared__ float red[1024];
     float acc = 0.0f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {  // 8 independent loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x[i + q * 1024];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; i < n; i += 1024) acc += x[i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {

@@ -18,7 +18,7 @@ namespace dr {
 // ---------------------------------------------------------------------------------------
 struct PlanLayout {
     int64_t hdr, keys_in, keys_out, vals_in, vals_out, flags, segidx, uniq, seg_start, temp, temp_bytes, total;
-    int64_t long_seg, long_cb, part_owner, partials, partial_rows;
+    int64_t long_seg, long_cb, part_owner, partials, partial_rows, msrc, mcoef;
 };
 
 // Segments longer than LONG_SEG contributions are summed in two passes so that a popular row does not
@@ -64,6 +64,8 @@ static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
     L->long_cb = take(max_long * 4);
     L->partial_rows = nn / DR_SEG_CHUNK + max_long + 1;
     L->part_owner = take(L->partial_rows * 4);
+    L->msrc = take(nn * 4);
+    L->mcoef = take(nn * 4);
     L->partials = take(L->partial_rows * (int64_t)(k_max > 0 ? k_max : 1) * 4);
     L->total = off;
     return 0;
@@ -147,9 +149,8 @@ struct SegArgs {
     int k;
     const float* src;
     int64_t src_rows;
-    const int32_t* src_idx;
-    const float* coef;
-    const int32_t* sorted_pos;
+    const int32_t* msrc;   // per SORTED contribution: source row (or -1 = skip)
+    const float* mcoef;    // per SORTED contribution: coefficient, NULL = 1
     const int32_t* uniq;
     const int32_t* seg_start;
     const int32_t* hdr;       // [0] nseg, [1] n long segments
@@ -161,23 +162,41 @@ struct SegArgs {
     OptP opt;
 };
 
+// per-contribution metadata in SORTED order, so that the segment kernels read it with plain sequential loads
+// instead of a position -> index -> row chain of dependent loads
+__global__ __launch_bounds__(256) void seg_meta_kernel(const int32_t* __restrict__ sorted_pos,
+                                                       const int32_t* __restrict__ src_idx,
+                                                       const float* __restrict__ coef, int64_t n, int64_t src_rows,
+                                                       int32_t* __restrict__ msrc, float* __restrict__ mcoef) {
+    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < n; y += (int64_t)gridDim.x * 256) {
+        const int p = sorted_pos[y];
+        const int64_t si = src_idx ? (int64_t)src_idx[p] : (int64_t)p;
+        msrc[y] = (si >= 0 && si < src_rows) ? (int32_t)si : -1;
+        if (coef) mcoef[y] = coef[p];
+    }
+}
+
 // sum of contributions [y0, y1) (one DR_SEG_CHUNK block) for vector column c, sequential in y;
-// the row loads of a block are independent of the running sum, so they are issued 4 at a time
+// the row loads of a block are independent of the running sum, so they are issued 8 at a time
 template <int V>
 __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int c, float (&acc)[V]) {
 #pragma unroll
     for (int x = 0; x < V; ++x) acc[x] = 0.0f;
+    const float* __restrict__ src = a.src;
     int y = y0;
-    for (; y + 4 <= y1; y += 4) {
-        float v[4][V];
-        float cf[4];
+    for (; y + 8 <= y1; y += 8) {
+        float v[8][V];
+        float cf[8];
+        int si[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int p = a.sorted_pos[y + q];
-            const int64_t si = a.src_idx ? (int64_t)a.src_idx[p] : (int64_t)p;
-            cf[q] = a.coef ? a.coef[p] : 1.0f;
-            if (si >= 0 && si < a.src_rows) {
-                vload<V>(v[q], a.src + si * a.k + c * V);
+        for (int q = 0; q < 8; ++q) {
+            si[q] = a.msrc[y + q];
+            cf[q] = a.mcoef ? a.mcoef[y + q] : 1.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (si[q] >= 0) {
+                vload<V>(v[q], src + (int64_t)si[q] * a.k + c * V);
             } else {
                 cf[q] = 0.0f;
 #pragma unroll
@@ -185,19 +204,18 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
 #pragma unroll
-            for (int x = 0; x < V; ++x) acc[x] = acc[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
+            for (int x = 0; x < V; ++x) acc[x] = acc[x] + (a.mcoef ? cf[q] * v[q][x] : v[q][x]);
         }
     }
     for (; y < y1; ++y) {
-        const int p = a.sorted_pos[y];
-        const int64_t si = a.src_idx ? (int64_t)a.src_idx[p] : (int64_t)p;
-        if (si < 0 || si >= a.src_rows) continue;
+        const int si = a.msrc[y];
+        if (si < 0) continue;
         float v[V];
-        vload<V>(v, a.src + si * a.k + c * V);
-        if (a.coef) {
-            const float cf = a.coef[p];
+        vload<V>(v, src + (int64_t)si * a.k + c * V);
+        if (a.mcoef) {
+            const float cf = a.mcoef[y];
 #pragma unroll
             for (int x = 0; x < V; ++x) v[x] = cf * v[x];
         }
@@ -266,6 +284,40 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
         if ((int64_t)r >= a.rows) continue;  // sentinel segment of out-of-range ids
         const int b = a.seg_start[s], e = a.seg_start[s + 1];
         if (e - b > LONG_SEG) continue;      // seg_long_kernel's
+        if (e - b <= 4) {
+            // the common case (mostly unique ids): resolve the <= 4 contributions once, then every vector
+            // column issues its source-row and destination-row loads together (same blocked order: one block)
+            const int len = e - b;
+            int64_t si[4];
+            float cf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                si[q] = -1;
+                cf[q] = 1.0f;
+                if (q < len) {
+                    si[q] = a.msrc[b + q];
+                    if (a.mcoef) cf[q] = a.mcoef[b + q];
+                }
+            }
+            for (int c = lane; c < cpr; c += LPR) {
+                float v[4][V], tot[V];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (si[q] >= 0) vload<V>(v[q], a.src + si[q] * a.k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (si[q] >= 0) {
+#pragma unroll
+                        for (int x = 0; x < V; ++x) tot[x] = tot[x] + (a.mcoef ? cf[q] * v[q][x] : v[q][x]);
+                    }
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = 0.0f + tot[x];
+                apply_row<V>(a, r, c, tot);
+            }
+            continue;
+        }
         for (int c = lane; c < cpr; c += LPR) {
             float tot[V], acc[V];
 #pragma unroll
@@ -525,9 +577,19 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
     a.k = k;
     a.src = src;
     a.src_rows = src_rows;
-    a.src_idx = src_idx;
-    a.coef = coef;
-    a.sorted_pos = (const int32_t*)(base + L.vals_out);
+    const int32_t* sorted_pos = (const int32_t*)(base + L.vals_out);
+    if (src_idx == nullptr && coef == nullptr && src_rows >= n) {
+        a.msrc = sorted_pos;  // contribution e reads row e: the sorted positions are the source rows
+        a.mcoef = nullptr;
+    } else {
+        int32_t* msrc = (int32_t*)(base + L.msrc);
+        float* mcoef = (float*)(base + L.mcoef);
+        DR_LAUNCH(seg_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, sorted_pos, src_idx, coef, n, src_rows, msrc,
+                  coef ? mcoef : (float*)nullptr);
+        DR_CHECK_LAUNCH("seg_meta_kernel");
+        a.msrc = msrc;
+        a.mcoef = coef ? mcoef : nullptr;
+    }
     a.uniq = (const int32_t*)(base + L.uniq);
     a.seg_start = (const int32_t*)(base + L.seg_start);
     a.hdr = (const int32_t*)(base + L.hdr);
