@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--eval-users", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel / eval / gather extras")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="build each batch's segment plans inside its own step (dr_bpr_step_f32) instead of one batch ahead")
     return ap.parse_args()
 
 
@@ -103,10 +106,18 @@ def main():
     n_slots = 2 if adam else 0
     stream = torch.cuda.current_stream()
 
+    # Adam's bias-corrected step size lives on the device (dr_adam_tick_f32, TF's beta-power variables), so a
+    # captured step keeps the exact per-step arithmetic when it is replayed
+    adam_state = K.AdamState(1e-3, 0.9, 0.999, device) if adam else None
+
     def opt_for(step):
         b1p, b2p = 0.9 ** step, 0.999 ** step
         return K.opt_params(K.OPT_ADAM if adam else K.OPT_SGD, lr=0.05, alpha=1e-3 * (1 - b2p) ** 0.5 / (1 - b1p),
                             beta1=0.9, beta2=0.999, eps=1e-7, reg=0.1, reg_mode=K.REG_TOUCHED)
+
+    opt_dev = K.opt_params(K.OPT_ADAM if adam else K.OPT_SGD, lr=0.05, beta1=0.9, beta2=0.999, eps=1e-7, reg=0.1,
+                           reg_mode=K.REG_TOUCHED, alpha_dev=adam_state.alpha if adam else None)
+    launch = "eager"
 
     batches = make_batches(args, rank, device)
     if world == 1:
@@ -116,11 +127,58 @@ def main():
         K.init_normal_(Q, 2, 0.01)
         sP = [torch.zeros_like(P) for _ in range(n_slots)] + [None, None]
         sQ = [torch.zeros_like(Q) for _ in range(n_slots)] + [None, None]
-        ws = K.StepWorkspace(B, k, args.users, args.items, K.REG_TOUCHED, device)
+        nb = len(batches)
+        wss = [K.StepWorkspace(B, k, args.users, args.items, K.REG_TOUCHED, device) for _ in range(nb)]
+        ws = wss[0]
+        side = torch.cuda.Stream(device=device)
+        pipelined = not args.no_pipeline
+
+        def eager_step(b):
+            """One step on resident batch b.  Pipelined: the id lists / segment plans of batch b+1 (they depend on
+            its ids only) are built on a second stream while this step's kernels run; every step still does all of
+            its own work inside the timed region, one batch ahead."""
+            u, i, j = batches[b]
+            if adam:
+                adam_state.tick()
+            if not pipelined:
+                return K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b])
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                K.bpr_plan(args.users, args.items, k, *batches[(b + 1) % nb], wss[(b + 1) % nb])
+            loss = K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b], planned=True)
+            cur.wait_stream(side)
+            return loss
+
+        if pipelined:
+            K.bpr_plan(args.users, args.items, k, *batches[0], wss[0])
+            launch = "eager, plans one batch ahead on a second stream"
 
         def step(t):
-            u, i, j = batches[t % len(batches)]
-            return K.bpr_step(P, Q, sP, sQ, u, i, j, opt_for(t + 1), ws)
+            return eager_step(t % nb)
+
+        if not args.no_graph:
+            # the step is ~40 short launches: replay it as one hipGraph per resident batch (launch-bound otherwise)
+            try:
+                eager_step(0)                       # creates helper streams / events outside capture
+                if pipelined:
+                    K.bpr_plan(args.users, args.items, k, *batches[0], wss[0])
+                torch.cuda.synchronize()
+                graphs = []
+                for b in range(nb):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        eager_step(b)
+                    graphs.append(g)
+                launch = "hipGraph replay, one graph per resident batch" + (
+                    "; plans one batch ahead on a parallel branch" if pipelined else "")
+
+                def step(t):                        # noqa: F811
+                    graphs[t % nb].replay()
+                    return wss[t % nb].loss
+            except Exception as e:                  # capture not available: measure the eager path and say so
+                launch = "eager (graph capture failed: %s)" % str(e).splitlines()[0][:120]
+                torch.cuda.synchronize()
     else:
         Pt = sh.ShardedTable(args.users, k, world, rank, device, n_slots)
         Qt = sh.ShardedTable(args.items, k, world, rank, device, n_slots)
@@ -161,7 +219,7 @@ def main():
                                "users~U, items~Zipf(1.05)" % (args.users // 10**6, args.items // 10**6, k, B,
                                                               "Adam" if adam else "SGD"),
                    "users": args.users, "items": args.items, "k": k, "batch_per_gpu": B,
-                   "optimizer": args.opt, "reg_mode": "touched",
+                   "optimizer": args.opt, "reg_mode": "touched", "launch": launch,
                    "parallelism": "single" if world == 1 else "row-sharded x%d (all-to-all)" % world},
         "last_loss_sum": last_loss,
     }

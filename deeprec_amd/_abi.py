@@ -14,7 +14,7 @@ class OptParams(C.Structure):
     """dr_opt_params (include/deeprec_amd.h)."""
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("alpha", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("rho", C.c_float), ("momentum", C.c_float),
-                ("reg", C.c_float), ("reg_mode", C.c_int32)]
+                ("reg", C.c_float), ("reg_mode", C.c_int32), ("alpha_dev", C.c_void_p)]
 
 
 _p = C.c_void_p
@@ -39,6 +39,9 @@ SIGNATURES = {
     "dr_pairwise_step_bytes": (_i64, [_i64, _i32, _i64, _i64, _i32]),
     "dr_bpr_step_f32": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _optp, _p, _p,
                                _i64, _p]),
+    "dr_bpr_plan_f32": (_i32, [_i64, _i64, _i32, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
+    "dr_bpr_step_planned_f32": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _optp, _p, _p,
+                                       _i64, _p]),
     "dr_bpr_forward_f32": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "dr_pointwise_forward_f32": (_i32, [_p, _p, _p, _p, _f, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p,
                                         _p, _p, _p]),
@@ -55,6 +58,7 @@ SIGNATURES = {
     "dr_topk_rank_f32": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "dr_score_matrix_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _i32, _p, _p, _i64, _p]),
     "dr_init_normal_f32": (_i32, [_p, _i64, C.c_uint64, _f, C.c_uint64, _p]),
+    "dr_adam_tick_f32": (_i32, [_p, _f, _f, _f, _p]),
     "dr_sum_f32": (_i32, [_p, _i64, _p, _p]),
 }
 

@@ -24,28 +24,53 @@ __global__ __launch_bounds__(256) void init_normal_kernel(float* __restrict__ w,
         w[i] = stddev * counter_normal(seed, offset + (uint64_t)i);
 }
 
-// One block, fixed order: thread t sums x[t], x[t+1024], ... sequentially, then a fixed LDS tree.
+// One block, fixed order: thread t owns the float4 groups t, t+1024, ... (up to 8 loads in flight, added in index
+// order, lanes of a group in order), then a fixed LDS tree; the tail is added by thread 0 at the end.
 __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     __shared__ float red[1024];
+    const bool vec = ((uintptr_t)x % 16) == 0;
+    const int64_t ngrp = vec ? n / 4 : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
     float acc = 0.0f;
     int64_t i = threadIdx.x;
-    for (; i + 7 * 1024 < n; i += 8 * 1024) {  // 8 independent loads in flight, added in index order
-        float v[8];
+    for (; i + 7 * 1024 < ngrp; i += 8 * 1024) {
+        float4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = x[i + q * 1024];
+        for (int q = 0; q < 8; ++q) v[q] = x4[i + q * 1024];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc += v[q];
+        for (int q = 0; q < 8; ++q) acc = (((acc + v[q].x) + v[q].y) + v[q].z) + v[q].w;
     }
-    for (; i < n; i += 1024) acc += x[i];
+    for (; i < ngrp; i += 1024) {
+        const float4 v = x4[i];
+        acc = (((acc + v.x) + v.y) + v.z) + v.w;
+    }
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
+    if (threadIdx.x == 0) {
+        float t = red[0];
+        for (int64_t e = ngrp * 4; e < n; ++e) t += x[e];
+        out[0] = t;
+    }
+}
+
+__global__ void adam_tick_kernel(float* state, float lr, float beta1, float beta2) {
+    const float b1p = state[0] * beta1, b2p = state[1] * beta2;
+    state[0] = b1p;
+    state[1] = b2p;
+    state[2] = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
 }
 }  // namespace dr
+
+extern "C" int32_t dr_adam_tick_f32(float* state, float lr, float beta1, float beta2, void* stream) {
+    DR_REQUIRE(state != nullptr, "dr_adam_tick_f32: state is NULL");
+    DR_LAUNCH(dr::adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, lr, beta1, beta2);
+    DR_CHECK_LAUNCH("dr_adam_tick_f32");
+    return DR_OK;
+}
 
 extern "C" const char* dr_last_error(void) { return dr::last_error_buf(); }
 extern "C" int32_t dr_version(void) { return 100; }

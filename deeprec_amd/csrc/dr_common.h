@@ -118,7 +118,13 @@ __device__ __forceinline__ float subwave_sum(float x) {
 struct OptP {
     int kind, reg_mode;
     float lr, alpha, omb1, omb2, eps, omrho, momentum, reg;
+    const float* alpha_dev;
 };
+// kernels call this once at entry: a device-resident alpha (graph replay) overrides the host value
+__device__ __forceinline__ OptP resolve(OptP o) {
+    if (o.alpha_dev) o.alpha = *o.alpha_dev;
+    return o;
+}
 static inline OptP make_optp(const dr_opt_params* o) {
     OptP p;
     p.kind = o->kind;
@@ -131,6 +137,7 @@ static inline OptP make_optp(const dr_opt_params* o) {
     p.omrho = 1.0f - o->rho;
     p.momentum = o->momentum;
     p.reg = o->reg;
+    p.alpha_dev = o->alpha_dev;
     return p;
 }
 

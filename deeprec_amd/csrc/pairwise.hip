@@ -7,11 +7,20 @@
 // Q is updated first from (g, P_old), P afterwards from the stash -- see DESIGN.md).
 #include "dr_common.h"
 
+#include <stdlib.h>
+
 namespace dr {
 
+struct SegSel {
+    uint32_t id_lo;
+    int part;
+    int pos_lo;
+};
 int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
                const int32_t* src_idx, const float* coef, int64_t n, void* plan, int64_t plan_bytes, int kind,
-               const dr_opt_params* opt, hipStream_t st);
+               const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel, int64_t n_table);
+int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, int64_t nu, int64_t ni, void* plan,
+                   int64_t plan_bytes, int k, hipStream_t st);
 int check_opt(const dr_opt_params* opt, const float* slot0, const float* slot1, const char* who);
 constexpr int KIND_ACC = -1;
 
@@ -24,7 +33,7 @@ __global__ __launch_bounds__(256) void bpr_forward_kernel(const float* __restric
                                                           const int32_t* __restrict__ u, const int32_t* __restrict__ i,
                                                           const int32_t* __restrict__ j, int64_t B,
                                                           float* __restrict__ g_out, float* __restrict__ loss_b,
-                                                          float* __restrict__ stash) {
+                                                          float* __restrict__ stash, float* __restrict__ coef2) {
     constexpr int SPB = 256 / LPR;
     const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
     const int cpr = k / V;
@@ -71,6 +80,10 @@ __global__ __launch_bounds__(256) void bpr_forward_kernel(const float* __restric
             if (lane == 0) {
                 g_out[b] = g;
                 loss_b[b] = l;
+                if (coef2) {  // coefficient list of the Q-side contributions [i ; j]
+                    coef2[b] = g;
+                    coef2[B + b] = -g;
+                }
             }
             for (int c = lane; c < cpr; c += LPR) {
                 float d[V];
@@ -95,20 +108,52 @@ __global__ __launch_bounds__(256) void bpr_forward_kernel(const float* __restric
     }
 }
 
-// idsQ = [i ; j], coefQ = [g ; -g], srcQ = [u ; u]
-__global__ __launch_bounds__(256) void bpr_qlists_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
-                                                         const int32_t* __restrict__ j, const float* __restrict__ g,
-                                                         int64_t B, int32_t* __restrict__ idsQ,
-                                                         float* __restrict__ coefQ, int32_t* __restrict__ srcQ) {
+// idsQ = [i ; j], srcQ = [u ; u]   (needs only the batch ids: runs beside the forward kernel)
+__global__ __launch_bounds__(256) void bpr_qids_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
+                                                       const int32_t* __restrict__ j, int64_t B,
+                                                       int32_t* __restrict__ idsQ, int32_t* __restrict__ srcQ) {
     for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
-        const float gb = g[b];
         idsQ[b] = i[b];
         idsQ[B + b] = j[b];
-        coefQ[b] = gb;
-        coefQ[B + b] = -gb;
         srcQ[b] = u[b];
         srcQ[B + b] = u[b];
     }
+}
+
+// coefQ = [g ; -g]
+__global__ __launch_bounds__(256) void bpr_qcoef_kernel(const float* __restrict__ g, int64_t B,
+                                                        float* __restrict__ coefQ) {
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+        const float gb = g[b];
+        coefQ[b] = gb;
+        coefQ[B + b] = -gb;
+    }
+}
+
+// Helper stream on which the segment plans of a step are built while the forward kernel runs on the caller's
+// stream (they depend on the batch ids only).  One per host thread and device, created on first use; fork/join
+// is done with events, so the caller still sees a single in-order stream (also under graph capture).
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, q_ready = nullptr, p_ready = nullptr;
+};
+static SideStream* side_stream() {
+    static thread_local SideStream side[32];
+    static const bool off = getenv("DR_NO_OVERLAP") != nullptr;
+    if (off) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    SideStream& x = side[dev];
+    if (!x.s) {
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) { x.s = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.q_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.p_ready, hipEventDisableTiming) != hipSuccess) {
+            x.s = nullptr;
+            return nullptr;
+        }
+    }
+    return &x;
 }
 
 // ---- pointwise forward: GMF BCE (gmf.py:66-75) / MF squared error (mf.py:50-55,96-97) ----
@@ -318,7 +363,7 @@ namespace dr {
 // stash_rows: B for BPR / pointwise, 2B for hinge.  dense tables only in DR_REG_DENSE.
 static int step_layout(int64_t B, int k, int64_t stash_rows, int64_t nu, int64_t ni, bool dense, StepLayout* L) {
     int64_t BB = B > 0 ? B : 1;
-    int64_t pa = dr_segment_plan_bytes(2 * BB, k), pb = dr_segment_plan_bytes(2 * BB, k);
+    int64_t pa = dr_segment_plan_bytes(3 * BB, k), pb = dr_segment_plan_bytes(2 * BB, k);
     if (pa < 0 || pb < 0) return -1;
     int64_t off = 0;
     auto take = [&](int64_t bytes) {
@@ -343,25 +388,37 @@ static int step_layout(int64_t B, int k, int64_t stash_rows, int64_t nu, int64_t
     return 0;
 }
 
-// One table's update from a contribution list, in either sparse (touched / none) or dense mode.
+// One table's update from a contribution list whose plan is already built, in either sparse (touched / none)
+// or dense mode.
+static int table_apply(float* T, float* s0, float* s1, int64_t rows, int k, int64_t n, const float* src,
+                       int64_t src_rows, const int32_t* src_idx, const float* coef, void* plan, int64_t plan_bytes,
+                       float* gdense, const dr_opt_params* opt, hipStream_t st, bool meta_ready = false,
+                       SegSel sel = SegSel{0, 0, 0}, int64_t n_table = 0) {
+    int rc;
+    if (opt->reg_mode == DR_REG_DENSE) {
+        DR_HIP(hipMemsetAsync(gdense, 0, (size_t)rows * k * 4, st));
+        rc = seg_launch(gdense, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, KIND_ACC, nullptr, st,
+                        meta_ready, sel, n_table);
+        if (rc != DR_OK) return rc;
+        return dr_dense_update_f32(T, s0, s1, gdense, rows * (int64_t)k, opt, st);
+    }
+    return seg_launch(T, s0, s1, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, opt->kind, opt, st, meta_ready, sel,
+                      n_table);
+}
+
 static int table_update(float* T, float* s0, float* s1, int64_t rows, int k, const int32_t* ids, int64_t n,
                         const float* src, int64_t src_rows, const int32_t* src_idx, const float* coef, void* plan,
                         int64_t plan_bytes, float* gdense, const dr_opt_params* opt, hipStream_t st) {
     int rc = dr_segment_plan(ids, n, 32, rows, plan, plan_bytes, st);
     if (rc != DR_OK) return rc;
-    if (opt->reg_mode == DR_REG_DENSE) {
-        DR_HIP(hipMemsetAsync(gdense, 0, (size_t)rows * k * 4, st));
-        rc = seg_launch(gdense, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, KIND_ACC, nullptr, st);
-        if (rc != DR_OK) return rc;
-        return dr_dense_update_f32(T, s0, s1, gdense, rows * (int64_t)k, opt, st);
-    }
-    return seg_launch(T, s0, s1, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, opt->kind, opt, st);
+    return table_apply(T, s0, s1, rows, k, n, src, src_rows, src_idx, coef, plan, plan_bytes, gdense, opt, st);
 }
 }  // namespace dr
 
-extern "C" int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t num_user, int64_t num_item, int32_t k,
-                                      const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, float* g_out,
-                                      float* loss_b, float* stash, void* stream) {
+namespace dr {
+static int bpr_forward(const float* P, const float* Q, int64_t num_user, int64_t num_item, int32_t k, const int32_t* u,
+                       const int32_t* i, const int32_t* j, int64_t B, float* g_out, float* loss_b, float* stash,
+                       float* coef2, void* stream) {
     DR_REQUIRE(num_user >= 0 && num_item >= 0 && k >= 1 && B >= 0, "dr_bpr_forward_f32: bad sizes");
     if (B == 0) return DR_OK;
     DR_REQUIRE(P && Q && u && i && j && g_out && loss_b && stash, "dr_bpr_forward_f32: NULL pointer");
@@ -371,7 +428,7 @@ extern "C" int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t nu
 #define DR_F(V_, L_)                                                                                                \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                          \
         DR_LAUNCH((bpr_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, st, P, Q,    \
-                           num_user, num_item, k, u, i, j, B, g_out, loss_b, stash);                                \
+                           num_user, num_item, k, u, i, j, B, g_out, loss_b, stash, coef2);                         \
         ok = true;                                                                                                  \
     }
     DR_SHAPE_DISPATCH(DR_F)
@@ -379,6 +436,13 @@ extern "C" int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t nu
     DR_REQUIRE(ok, "dr_bpr_forward_f32: unsupported k=%d", k);
     DR_CHECK_LAUNCH("dr_bpr_forward_f32");
     return DR_OK;
+}
+}  // namespace dr
+
+extern "C" int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t num_user, int64_t num_item, int32_t k,
+                                      const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, float* g_out,
+                                      float* loss_b, float* stash, void* stream) {
+    return dr::bpr_forward(P, Q, num_user, num_item, k, u, i, j, B, g_out, loss_b, stash, nullptr, stream);
 }
 
 extern "C" int64_t dr_pairwise_step_bytes(int64_t B, int32_t k, int64_t num_user, int64_t num_item,
@@ -389,19 +453,27 @@ extern "C" int64_t dr_pairwise_step_bytes(int64_t B, int32_t k, int64_t num_user
     return L.total;
 }
 
-extern "C" int32_t dr_bpr_step_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q, float* Qslot0,
-                                   float* Qslot1, int64_t num_item, int32_t k, const int32_t* u, const int32_t* i,
-                                   const int32_t* j, int64_t B, const dr_opt_params* opt, float* loss_out, void* ws,
-                                   int64_t ws_bytes, void* stream) {
+namespace dr {
+// mode 0: whole step; 1: only the id lists + both segment plans (they depend on the batch ids alone);
+// 2: the step, with the plans of THIS batch already in ws (built by a mode-1 call)
+static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q, float* Qslot0,
+                         float* Qslot1, int64_t num_item, int32_t k, const int32_t* u, const int32_t* i,
+                         const int32_t* j, int64_t B, const dr_opt_params* opt, int reg_mode, float* loss_out, void* ws,
+                         int64_t ws_bytes, void* stream, int mode) {
     DR_REQUIRE(num_user >= 0 && num_item >= 0 && k >= 1 && B >= 0, "dr_bpr_step_f32: bad sizes");
-    int rc = check_opt(opt, Pslot0, Pslot1, "dr_bpr_step_f32(P)");
-    if (rc != DR_OK) return rc;
-    rc = check_opt(opt, Qslot0, Qslot1, "dr_bpr_step_f32(Q)");
-    if (rc != DR_OK) return rc;
-    DR_REQUIRE(P && Q && ws && ((uintptr_t)ws % 256 == 0), "dr_bpr_step_f32: NULL / misaligned pointer");
+    int rc;
+    if (mode != 1) {
+        rc = check_opt(opt, Pslot0, Pslot1, "dr_bpr_step_f32(P)");
+        if (rc != DR_OK) return rc;
+        rc = check_opt(opt, Qslot0, Qslot1, "dr_bpr_step_f32(Q)");
+        if (rc != DR_OK) return rc;
+        DR_REQUIRE(P && Q, "dr_bpr_step_f32: table pointer is NULL");
+        reg_mode = opt->reg_mode;
+    }
+    DR_REQUIRE(ws && ((uintptr_t)ws % 256 == 0), "dr_bpr_step_f32: NULL / misaligned workspace");
     DR_REQUIRE(B == 0 || (u && i && j), "dr_bpr_step_f32: id pointer is NULL");
     StepLayout L;
-    if (step_layout(B, k, 2 * B, num_user, num_item, opt->reg_mode == DR_REG_DENSE, &L) != 0) return DR_ERR_LAUNCH;
+    if (step_layout(B, k, 2 * B, num_user, num_item, reg_mode == DR_REG_DENSE, &L) != 0) return DR_ERR_LAUNCH;
     if (ws_bytes < L.total)
         DR_FAIL(DR_ERR_WORKSPACE, "dr_bpr_step_f32: workspace %lld < required %lld", (long long)ws_bytes,
                 (long long)L.total);
@@ -413,23 +485,65 @@ extern "C" int32_t dr_bpr_step_f32(float* P, float* Pslot0, float* Pslot1, int64
     int32_t* idsQ = (int32_t*)(base + L.idsA);
     float* coefQ = (float*)(base + L.coef);
     int32_t* srcQ = (int32_t*)(base + L.src);
-    if (B > 0) {
-        rc = dr_bpr_forward_f32(P, Q, num_user, num_item, k, u, i, j, B, g, loss_b, stash, st);
-        if (rc != DR_OK) return rc;
-        DR_LAUNCH(bpr_qlists_kernel, dim3(grid_for(B, 256)), dim3(256), 0, st, u, i, j, g, B, idsQ, coefQ, srcQ);
-        DR_CHECK_LAUNCH("bpr_qlists_kernel");
+    const bool any = B > 0 || reg_mode == DR_REG_DENSE;
+    // Fork (mode 0): the id lists and both segment plans depend on the batch ids only, so they are built on the
+    // helper stream while the forward kernel runs here; the updates join on events.
+    SideStream* side = (mode == 0 && B > 0) ? side_stream() : nullptr;
+    hipStream_t ps = side ? side->s : st;
+    if (side) {
+        DR_HIP(hipEventRecord(side->fork, st));
+        DR_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
     }
-    if (B > 0 || opt->reg_mode == DR_REG_DENSE) {
-        // Q first: its gradient needs the pre-step P rows.  P afterwards from the stash.
-        rc = table_update(Q, Qslot0, Qslot1, num_item, k, idsQ, 2 * B, P, num_user, srcQ, coefQ, base + L.planA,
-                          L.plan_bytesA, (float*)(base + L.gdenseQ), opt, st);
+    if (mode != 1 && B > 0) {  // enqueued first: the host then feeds the helper stream while this runs
+        rc = bpr_forward(P, Q, num_user, num_item, k, u, i, j, B, g, loss_b, stash, coefQ, st);
         if (rc != DR_OK) return rc;
-        rc = table_update(P, Pslot0, Pslot1, num_user, k, u, B, stash, B, nullptr, nullptr, base + L.planB,
-                          L.plan_bytesB, (float*)(base + L.gdenseP), opt, st);
+    }
+    if (mode != 2) {
+        if (any) {
+            rc = plan_build_bpr(u, i, j, B, num_user, num_item, base + L.planA, L.plan_bytesA, k, ps);
+            if (rc != DR_OK) return rc;
+            if (side) DR_HIP(hipEventRecord(side->q_ready, side->s));
+        }
+        if (mode == 1) return DR_OK;
+    }
+    if (any) {
+        // one combined plan: segments below the split are P rows (contributions = stash rows b), the others Q
+        // rows (key - num_user; contributions (+-g_b) * P[u_b]).  Q first: its gradient needs the pre-step P rows.
+        if (side) DR_HIP(hipStreamWaitEvent(st, side->q_ready, 0));
+        rc = table_apply(Q, Qslot0, Qslot1, num_item, k, 3 * B, P, num_user, nullptr, coefQ, base + L.planA,
+                         L.plan_bytesA, (float*)(base + L.gdenseQ), opt, st, true,
+                         SegSel{(uint32_t)num_user, 2, (int)B}, 2 * B);
+        if (rc != DR_OK) return rc;
+        rc = table_apply(P, Pslot0, Pslot1, num_user, k, 3 * B, stash, B, nullptr, nullptr, base + L.planA,
+                         L.plan_bytesA, (float*)(base + L.gdenseP), opt, st, true, SegSel{0, 1, 0}, B);
         if (rc != DR_OK) return rc;
     }
     if (loss_out) return dr_sum_f32(loss_b, B, loss_out, st);
     return DR_OK;
+}
+}  // namespace dr
+
+extern "C" int32_t dr_bpr_step_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q, float* Qslot0,
+                                   float* Qslot1, int64_t num_item, int32_t k, const int32_t* u, const int32_t* i,
+                                   const int32_t* j, int64_t B, const dr_opt_params* opt, float* loss_out, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+    return bpr_step_impl(P, Pslot0, Pslot1, num_user, Q, Qslot0, Qslot1, num_item, k, u, i, j, B, opt, 0, loss_out, ws,
+                         ws_bytes, stream, 0);
+}
+
+extern "C" int32_t dr_bpr_plan_f32(int64_t num_user, int64_t num_item, int32_t k, const int32_t* u, const int32_t* i,
+                                   const int32_t* j, int64_t B, int32_t reg_mode, void* ws, int64_t ws_bytes,
+                                   void* stream) {
+    return bpr_step_impl(nullptr, nullptr, nullptr, num_user, nullptr, nullptr, nullptr, num_item, k, u, i, j, B, nullptr,
+                         reg_mode, nullptr, ws, ws_bytes, stream, 1);
+}
+
+extern "C" int32_t dr_bpr_step_planned_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q,
+                                           float* Qslot0, float* Qslot1, int64_t num_item, int32_t k, const int32_t* u,
+                                           const int32_t* i, const int32_t* j, int64_t B, const dr_opt_params* opt,
+                                           float* loss_out, void* ws, int64_t ws_bytes, void* stream) {
+    return bpr_step_impl(P, Pslot0, Pslot1, num_user, Q, Qslot0, Qslot1, num_item, k, u, i, j, B, opt, 0, loss_out, ws,
+                         ws_bytes, stream, 2);
 }
 
 extern "C" int32_t dr_pointwise_forward_f32(const float* P, const float* Q, const float* BU, const float* BI, float mu,

@@ -9,6 +9,7 @@
 #include "dr_common.h"
 
 #include <cstring>
+#include <stdlib.h>
 #include <rocprim/rocprim.hpp>
 
 namespace dr {
@@ -96,16 +97,60 @@ __global__ __launch_bounds__(256) void plan_finalize_kernel(const uint32_t* __re
                                                             const int32_t* __restrict__ flags,
                                                             const int32_t* __restrict__ segidx, int64_t n,
                                                             int32_t* __restrict__ uniq, int32_t* __restrict__ seg_start,
-                                                            int32_t* __restrict__ hdr) {
+                                                            int32_t* __restrict__ hdr, uint32_t split_key) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         if (flags[e]) {
             uniq[segidx[e]] = (int32_t)sk[e];
             seg_start[segidx[e]] = (int32_t)e;
+            // hdr[3]: first segment whose key is >= split_key (two tables sorted as one list)
+            if (sk[e] >= split_key && (e == 0 || sk[e - 1] < split_key)) hdr[3] = segidx[e];
         }
         if (e == n - 1) {
             int32_t ns = segidx[e] + flags[e];
             hdr[0] = ns;
             seg_start[ns] = (int32_t)n;
+            if (sk[e] < split_key) hdr[3] = ns;
+        }
+    }
+}
+
+// combined key list of one BPR batch: [u ; num_user + i ; num_user + j], invalid ids -> sentinel num_user + num_item
+__global__ __launch_bounds__(256) void plan_keys_bpr_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
+                                                            const int32_t* __restrict__ j, int64_t B, int64_t nu,
+                                                            int64_t ni, uint32_t* __restrict__ keys,
+                                                            int32_t* __restrict__ vals, int32_t* __restrict__ hdr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr[1] = 0;
+        hdr[2] = 0;
+    }
+    const uint32_t sentinel = (uint32_t)(nu + ni);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 3 * B; e += (int64_t)gridDim.x * 256) {
+        uint32_t key;
+        if (e < B) {
+            const int64_t id = u[e];
+            key = (id < 0 || id >= nu) ? sentinel : (uint32_t)id;
+        } else {
+            const int64_t id = (e < 2 * B) ? i[e - B] : j[e - 2 * B];
+            key = (id < 0 || id >= ni) ? sentinel : (uint32_t)(nu + id);
+        }
+        keys[e] = key;
+        vals[e] = (int32_t)e;
+    }
+}
+
+// source rows of the sorted contributions of a BPR batch: position p < B reads stash row p (P side), position
+// B + x reads the user row u[x mod B] (Q side: g_b * p_u)
+__global__ __launch_bounds__(256) void bpr_meta_kernel(const int32_t* __restrict__ sorted_pos,
+                                                       const int32_t* __restrict__ u, int64_t B, int64_t nu,
+                                                       int32_t* __restrict__ msrc) {
+    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < 3 * B; y += (int64_t)gridDim.x * 256) {
+        const int p = sorted_pos[y];
+        if (p < B) {
+            msrc[y] = p;
+        } else {
+            const int64_t x = (p - B) % B;
+            const int64_t id = u[x];
+            msrc[y] = (id >= 0 && id < nu) ? (int32_t)id : -1;
         }
     }
 }
@@ -114,6 +159,7 @@ __global__ void plan_empty_kernel(int32_t* hdr, int32_t* seg_start) {
     hdr[0] = 0;
     hdr[1] = 0;
     hdr[2] = 0;
+    hdr[3] = 0;
     seg_start[0] = 0;
 }
 
@@ -141,6 +187,37 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
 // ---------------------------------------------------------------------------------------
 constexpr int KIND_ACC = -1;
 
+// helper stream of the calling host thread for `main`'s device; returns `main` when it cannot be had
+hipStream_t seg_side_stream(hipStream_t main, hipEvent_t* fork, hipEvent_t* join) {
+    struct Side {
+        hipStream_t s = nullptr;
+        hipEvent_t fork = nullptr, join = nullptr;
+    };
+    static thread_local Side side[32];
+    static const bool off = getenv("DR_NO_OVERLAP") != nullptr;
+    int dev = 0;
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return main;
+    Side& x = side[dev];
+    if (!x.s) {
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
+            x.s = nullptr;
+            return main;
+        }
+    }
+    if (hipEventRecord(x.fork, main) != hipSuccess || hipStreamWaitEvent(x.s, x.fork, 0) != hipSuccess) return main;
+    *fork = x.fork;
+    *join = x.join;
+    return x.s;
+}
+
+struct SegSel {
+    uint32_t id_lo;
+    int part;
+    int pos_lo;
+};
+
 struct SegArgs {
     float* table;
     float* slot0;
@@ -150,7 +227,11 @@ struct SegArgs {
     const float* src;
     int64_t src_rows;
     const int32_t* msrc;   // per SORTED contribution: source row (or -1 = skip)
-    const float* mcoef;    // per SORTED contribution: coefficient, NULL = 1
+    const float* coef;     // per contribution in ORIGINAL order (read through spos), NULL = 1
+    const int32_t* spos;   // sorted position list
+    uint32_t id_lo;        // destination row = segment key - id_lo (combined two-table plans)
+    int part;              // 0: all segments, 1: those below the plan's split, 2: those at / above it
+    int pos_lo;            // coef is indexed by (position - pos_lo)
     const int32_t* uniq;
     const int32_t* seg_start;
     const int32_t* hdr;       // [0] nseg, [1] n long segments
@@ -165,14 +246,12 @@ struct SegArgs {
 // per-contribution metadata in SORTED order, so that the segment kernels read it with plain sequential loads
 // instead of a position -> index -> row chain of dependent loads
 __global__ __launch_bounds__(256) void seg_meta_kernel(const int32_t* __restrict__ sorted_pos,
-                                                       const int32_t* __restrict__ src_idx,
-                                                       const float* __restrict__ coef, int64_t n, int64_t src_rows,
-                                                       int32_t* __restrict__ msrc, float* __restrict__ mcoef) {
+                                                       const int32_t* __restrict__ src_idx, int64_t n,
+                                                       int64_t src_rows, int32_t* __restrict__ msrc) {
     for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < n; y += (int64_t)gridDim.x * 256) {
         const int p = sorted_pos[y];
         const int64_t si = src_idx ? (int64_t)src_idx[p] : (int64_t)p;
         msrc[y] = (si >= 0 && si < src_rows) ? (int32_t)si : -1;
-        if (coef) mcoef[y] = coef[p];
     }
 }
 
@@ -191,7 +270,7 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             si[q] = a.msrc[y + q];
-            cf[q] = a.mcoef ? a.mcoef[y + q] : 1.0f;
+            cf[q] = a.coef ? a.coef[a.spos[y + q] - a.pos_lo] : 1.0f;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -206,7 +285,7 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
 #pragma unroll
-            for (int x = 0; x < V; ++x) acc[x] = acc[x] + (a.mcoef ? cf[q] * v[q][x] : v[q][x]);
+            for (int x = 0; x < V; ++x) acc[x] = acc[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
         }
     }
     for (; y < y1; ++y) {
@@ -214,8 +293,8 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
         if (si < 0) continue;
         float v[V];
         vload<V>(v, src + (int64_t)si * a.k + c * V);
-        if (a.mcoef) {
-            const float cf = a.mcoef[y];
+        if (a.coef) {
+            const float cf = a.coef[a.spos[y] - a.pos_lo];
 #pragma unroll
             for (int x = 0; x < V; ++x) v[x] = cf * v[x];
         }
@@ -274,14 +353,16 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, f
 // short segments: one sub-wave per segment
 template <int V, int LPR>
 __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
+    a.opt = resolve(a.opt);
     constexpr int SPB = 256 / LPR;  // segments per block pass
     const int sub = threadIdx.x / LPR;
     const int lane = threadIdx.x % LPR;
     const int cpr = a.k / V;
-    const int nseg = a.hdr[0];
-    for (int s = blockIdx.x * SPB + sub; s < nseg; s += gridDim.x * SPB) {
-        const uint32_t r = (uint32_t)a.uniq[s];
-        if ((int64_t)r >= a.rows) continue;  // sentinel segment of out-of-range ids
+    const int s_lo = (a.part == 2) ? a.hdr[3] : 0;
+    const int s_hi = (a.part == 1) ? a.hdr[3] : a.hdr[0];
+    for (int s = s_lo + blockIdx.x * SPB + sub; s < s_hi; s += gridDim.x * SPB) {
+        const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
+        if ((int64_t)r >= a.rows) continue;  // sentinel segment of out-of-range ids / the other table's rows
         const int b = a.seg_start[s], e = a.seg_start[s + 1];
         if (e - b > LONG_SEG) continue;      // seg_long_kernel's
         if (e - b <= 4) {
@@ -296,7 +377,7 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
                 cf[q] = 1.0f;
                 if (q < len) {
                     si[q] = a.msrc[b + q];
-                    if (a.mcoef) cf[q] = a.mcoef[b + q];
+                    if (a.coef) cf[q] = a.coef[a.spos[b + q] - a.pos_lo];
                 }
             }
             for (int c = lane; c < cpr; c += LPR) {
@@ -310,7 +391,7 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
                 for (int q = 0; q < 4; ++q)
                     if (si[q] >= 0) {
 #pragma unroll
-                        for (int x = 0; x < V; ++x) tot[x] = tot[x] + (a.mcoef ? cf[q] * v[q][x] : v[q][x]);
+                        for (int x = 0; x < V; ++x) tot[x] = tot[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
                     }
 #pragma unroll
                 for (int x = 0; x < V; ++x) tot[x] = 0.0f + tot[x];
@@ -343,6 +424,7 @@ __global__ __launch_bounds__(256) void seg_long_partial_kernel(SegArgs a) {
     for (int pr = blockIdx.x * SPB + sub; pr < nparts; pr += gridDim.x * SPB) {
         const int l = a.part_owner[pr];
         const int s = a.long_seg[l];
+        if ((int64_t)((uint32_t)a.uniq[s] - a.id_lo) >= a.rows) continue;  // not this table's segment
         const int ch = pr - a.long_cb[l];
         const int b = a.seg_start[s], e = a.seg_start[s + 1];
         const int c0 = b + ch * DR_SEG_CHUNK;
@@ -358,6 +440,7 @@ __global__ __launch_bounds__(256) void seg_long_partial_kernel(SegArgs a) {
 // long segments, pass 2: one sub-wave per long segment adds its block partials in block order
 template <int V, int LPR>
 __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
+    a.opt = resolve(a.opt);
     constexpr int SPB = 256 / LPR;
     const int sub = threadIdx.x / LPR;
     const int lane = threadIdx.x % LPR;
@@ -365,7 +448,7 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
     const int nlong = a.hdr[1];
     for (int l = blockIdx.x * SPB + sub; l < nlong; l += gridDim.x * SPB) {
         const int s = a.long_seg[l];
-        const uint32_t r = (uint32_t)a.uniq[s];
+        const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
         if ((int64_t)r >= a.rows) continue;
         const int nch = (a.seg_start[s + 1] - a.seg_start[s] + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK;
         const float* part = a.partials + (int64_t)a.long_cb[l] * a.k;
@@ -396,15 +479,25 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
 }
 
 template <int V, int LPR>
-static void launch_seg(const SegArgs& a, int64_t n, hipStream_t st) {
+static void launch_seg(const SegArgs& a, int64_t n, hipStream_t main) {
     constexpr int SPB = 256 / LPR;
     int grid = grid_for(n, 1, SPB);
-    DR_LAUNCH((seg_update_kernel<V, LPR>), dim3(grid), dim3(256), 0, st, a);
+    // short and long segments own disjoint destination rows: the two long-segment passes run on a helper
+    // stream beside the short-segment kernel (fork / join with events; also valid under graph capture)
+    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t st = main;
+    if (n > LONG_SEG) st = seg_side_stream(main, &fork, &join);
+    if (st == main) DR_LAUNCH((seg_update_kernel<V, LPR>), dim3(grid), dim3(256), 0, main, a);
     if (n > LONG_SEG) {
         // partial rows <= n / DR_SEG_CHUNK + n / LONG_SEG ; long segments <= n / LONG_SEG
         DR_LAUNCH((seg_long_partial_kernel<V, LPR>), dim3(grid_for(n / DR_SEG_CHUNK + n / LONG_SEG + 1, 1, SPB)),
                   dim3(256), 0, st, a);
         DR_LAUNCH((seg_long_combine_kernel<V, LPR>), dim3(grid_for(n / LONG_SEG + 1, 1, SPB)), dim3(256), 0, st, a);
+        if (st != main) {  // the (small) long-segment passes were enqueued first so that they are not starved
+            (void)hipEventRecord(join, st);
+            DR_LAUNCH((seg_update_kernel<V, LPR>), dim3(grid), dim3(256), 0, main, a);
+            (void)hipStreamWaitEvent(main, join, 0);
+        }
     }
 }
 
@@ -429,6 +522,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ w, float* __restrict__ s0p,
                                                            float* __restrict__ s1p, const float* __restrict__ grad,
                                                            int64_t count, OptP o) {
+    o = resolve(o);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
         float wi = w[i];
         float g = grad ? grad[i] : 0.0f;
@@ -480,6 +574,69 @@ __global__ __launch_bounds__(256) void rownorm_clip_kernel(float* __restrict__ t
 
 using namespace dr;
 
+namespace dr {
+// shared tail of the plan builders: keys_in / vals_in are filled; sort, run boundaries, long-segment list
+static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_bit, uint32_t split_key, hipStream_t st) {
+    int32_t* hdr = (int32_t*)(base + L.hdr);
+    uint32_t* keys_in = (uint32_t*)(base + L.keys_in);
+    uint32_t* keys_out = (uint32_t*)(base + L.keys_out);
+    int32_t* vals_in = (int32_t*)(base + L.vals_in);
+    int32_t* vals_out = (int32_t*)(base + L.vals_out);
+    int32_t* flags = (int32_t*)(base + L.flags);
+    int32_t* segidx = (int32_t*)(base + L.segidx);
+    int32_t* uniq = (int32_t*)(base + L.uniq);
+    int32_t* seg_start = (int32_t*)(base + L.seg_start);
+    const int grid = grid_for(n, 256);
+    size_t tb = (size_t)L.temp_bytes;
+    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, keys_in, keys_out, vals_in,
+                                                               vals_out, (size_t)n, 0u, end_bit, st, false)));
+    DR_LAUNCH(plan_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, flags);
+    DR_CHECK_LAUNCH("plan_heads_kernel");
+    tb = (size_t)L.temp_bytes;
+    DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, segidx, (int32_t)0, (size_t)n,
+                                                             rocprim::plus<int32_t>(), st, false)));
+    DR_LAUNCH(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start, hdr,
+              split_key);
+    DR_CHECK_LAUNCH("plan_finalize_kernel");
+    if (n > LONG_SEG) {
+        DR_LAUNCH(plan_long_kernel, dim3(grid), dim3(256), 0, st, seg_start, hdr, (int32_t*)(base + L.long_seg),
+                  (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), n);
+        DR_CHECK_LAUNCH("plan_long_kernel");
+    }
+    return DR_OK;
+}
+
+// One plan for both tables of a BPR batch (3B contributions: [u ; i ; j], Q keys offset by num_user) plus the
+// source-row list of the sorted contributions.  Half the launches of two separate plans.
+int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, int64_t nu, int64_t ni, void* plan,
+                   int64_t plan_bytes, int k, hipStream_t st) {
+    const int64_t n = 3 * B;
+    DR_REQUIRE(n < (1ll << 31) - 1 && nu + ni < (1ll << 32) - 2, "bpr plan: batch / tables too large for 32-bit keys");
+    PlanLayout L;
+    if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "bpr plan: workspace %lld < required %lld", (long long)plan_bytes, (long long)L.total);
+    char* base = (char*)plan;
+    int32_t* hdr = (int32_t*)(base + L.hdr);
+    if (n == 0) {
+        DR_LAUNCH(plan_empty_kernel, dim3(1), dim3(1), 0, st, hdr, (int32_t*)(base + L.seg_start));
+        DR_CHECK_LAUNCH("bpr plan (empty)");
+        return DR_OK;
+    }
+    DR_LAUNCH(plan_keys_bpr_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, u, i, j, B, nu, ni,
+              (uint32_t*)(base + L.keys_in), (int32_t*)(base + L.vals_in), hdr);
+    DR_CHECK_LAUNCH("plan_keys_bpr_kernel");
+    unsigned end_bit = 1;
+    while (end_bit < 32 && ((uint64_t)(nu + ni) >> end_bit) != 0) ++end_bit;
+    int rc = plan_finish(base, L, n, end_bit, (uint32_t)nu, st);
+    if (rc != DR_OK) return rc;
+    DR_LAUNCH(bpr_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int32_t*)(base + L.vals_out), u, B, nu,
+              (int32_t*)(base + L.msrc));
+    DR_CHECK_LAUNCH("bpr_meta_kernel");
+    return DR_OK;
+}
+}  // namespace dr
+
 extern "C" int64_t dr_segment_plan_bytes(int64_t n, int32_t k_max) {
     if (n < 0 || k_max < 1) return DR_ERR_ARG;
     PlanLayout L;
@@ -525,24 +682,7 @@ extern "C" int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, 
     DR_CHECK_LAUNCH("plan_keys_kernel");
     unsigned end_bit = 1;
     while (end_bit < 32 && ((uint64_t)rows >> end_bit) != 0) ++end_bit;  // enough bits for the sentinel `rows`
-    size_t tb = (size_t)L.temp_bytes;
-    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, keys_in, keys_out, vals_in,
-                                                               vals_out, (size_t)n, 0u, end_bit, st, false)));
-    DR_LAUNCH(plan_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, flags);
-    DR_CHECK_LAUNCH("plan_heads_kernel");
-    tb = (size_t)L.temp_bytes;
-    DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, segidx, (int32_t)0, (size_t)n,
-                                                             rocprim::plus<int32_t>(), st, false)));
-    DR_LAUNCH(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start,
-                       hdr);
-    DR_CHECK_LAUNCH("plan_finalize_kernel");
-    if (n > LONG_SEG) {
-        DR_LAUNCH(plan_long_kernel, dim3(grid), dim3(256), 0, st, seg_start, hdr,
-                           (int32_t*)(base + L.long_seg), (int32_t*)(base + L.long_cb),
-                           (int32_t*)(base + L.part_owner), n);
-        DR_CHECK_LAUNCH("plan_long_kernel");
-    }
-    return DR_OK;
+    return plan_finish(base, L, n, end_bit, 0xFFFFFFFFu, st);
 }
 
 extern "C" int32_t dr_segment_plan_view(void* plan, int64_t n, const int32_t** sorted_pos, const int32_t** uniq_ids,
@@ -560,9 +700,26 @@ extern "C" int32_t dr_segment_plan_view(void* plan, int64_t n, const int32_t** s
 
 namespace dr {
 // shared by scatter-add, sparse update and the fused steps
+// msrc[y] = source row of the y-th sorted contribution; depends on the ids and src_idx only, so fused steps
+// run it with the plan, off the critical path
+int seg_meta(void* plan, int64_t n, const int32_t* src_idx, int64_t src_rows, hipStream_t st) {
+    PlanLayout L;
+    if (plan_layout(n, 1, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (n == 0) return DR_OK;
+    char* base = (char*)plan;
+    DR_LAUNCH(seg_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int32_t*)(base + L.vals_out), src_idx, n,
+              src_rows, (int32_t*)(base + L.msrc));
+    DR_CHECK_LAUNCH("seg_meta_kernel");
+    return DR_OK;
+}
+
+hipStream_t seg_side_stream(hipStream_t main, hipEvent_t* fork, hipEvent_t* join);
+
+// n: contributions the plan was built for; n_table: those of them that belong to this table (grid sizing);
+// sel: which part of a combined two-table plan this launch owns ({0,0,0} = an ordinary single-table plan)
 int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
                const int32_t* src_idx, const float* coef, int64_t n, void* plan, int64_t plan_bytes, int kind,
-               const dr_opt_params* opt, hipStream_t st) {
+               const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel, int64_t n_table) {
     PlanLayout L;
     if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
     if (plan_bytes < L.total)
@@ -578,17 +735,21 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
     a.src = src;
     a.src_rows = src_rows;
     const int32_t* sorted_pos = (const int32_t*)(base + L.vals_out);
-    if (src_idx == nullptr && coef == nullptr && src_rows >= n) {
+    a.spos = sorted_pos;
+    a.coef = coef;
+    a.id_lo = sel.id_lo;
+    a.part = sel.part;
+    a.pos_lo = sel.pos_lo;
+    if (meta_ready) {
+        a.msrc = (const int32_t*)(base + L.msrc);
+    } else if (src_idx == nullptr && src_rows >= n) {
         a.msrc = sorted_pos;  // contribution e reads row e: the sorted positions are the source rows
-        a.mcoef = nullptr;
     } else {
-        int32_t* msrc = (int32_t*)(base + L.msrc);
-        float* mcoef = (float*)(base + L.mcoef);
-        DR_LAUNCH(seg_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, sorted_pos, src_idx, coef, n, src_rows, msrc,
-                  coef ? mcoef : (float*)nullptr);
-        DR_CHECK_LAUNCH("seg_meta_kernel");
-        a.msrc = msrc;
-        a.mcoef = coef ? mcoef : nullptr;
+        if (!meta_ready) {
+            int rc = seg_meta(plan, n, src_idx, src_rows, st);
+            if (rc != DR_OK) return rc;
+        }
+        a.msrc = (const int32_t*)(base + L.msrc);
     }
     a.uniq = (const int32_t*)(base + L.uniq);
     a.seg_start = (const int32_t*)(base + L.seg_start);
@@ -600,7 +761,7 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
     a.kind = kind;
     if (opt) a.opt = make_optp(opt);
     else memset(&a.opt, 0, sizeof(a.opt));
-    if (dispatch_seg(a, n, st) != 0) DR_FAIL(DR_ERR_ARG, "segment kernel: unsupported k=%d", k);
+    if (dispatch_seg(a, n_table > 0 ? n_table : n, st) != 0) DR_FAIL(DR_ERR_ARG, "segment kernel: unsupported k=%d", k);
     DR_CHECK_LAUNCH("seg_update_kernel");
     return DR_OK;
 }
@@ -624,7 +785,7 @@ extern "C" int32_t dr_scatter_add_sorted_f32(float* gtable, int64_t rows, int32_
     if (n == 0) return DR_OK;
     DR_REQUIRE(gtable && src && plan, "dr_scatter_add_sorted_f32: NULL pointer");
     return seg_launch(gtable, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, KIND_ACC,
-                      nullptr, (hipStream_t)stream);
+                      nullptr, (hipStream_t)stream, false, SegSel{0, 0, 0}, 0);
 }
 
 extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* slot1, int64_t rows, int32_t k,
@@ -639,7 +800,7 @@ extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* s
     if (n == 0) return DR_OK;
     DR_REQUIRE(table && src && plan, "dr_sparse_row_update_f32: NULL pointer");
     return seg_launch(table, slot0, slot1, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, opt->kind, opt,
-                      (hipStream_t)stream);
+                      (hipStream_t)stream, false, SegSel{0, 0, 0}, 0);
 }
 
 extern "C" int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, const float* grad, int64_t count,

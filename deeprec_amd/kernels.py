@@ -53,8 +53,23 @@ def _i32(t, name):
 
 
 def opt_params(kind, lr=0.0, alpha=0.0, beta1=0.9, beta2=0.999, eps=1e-8, rho=0.9, momentum=0.0, reg=0.0,
-               reg_mode=REG_TOUCHED):
-    return OptParams(kind, lr, alpha, beta1, beta2, eps, rho, momentum, reg, reg_mode)
+               reg_mode=REG_TOUCHED, alpha_dev=None):
+    """alpha_dev: optional device float tensor (1 element) overriding alpha at kernel run time (graph replay)."""
+    return OptParams(kind, lr, alpha, beta1, beta2, eps, rho, momentum, reg, reg_mode,
+                     alpha_dev.data_ptr() if alpha_dev is not None else None)
+
+
+class AdamState:
+    """Device-side beta-power state (dr_adam_tick_f32): tick() once per step, pass .alpha to opt_params."""
+
+    def __init__(self, lr, beta1=0.9, beta2=0.999, device="cuda:0"):
+        self.lr, self.beta1, self.beta2 = float(lr), float(beta1), float(beta2)
+        self.state = torch.tensor([1.0, 1.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.alpha = self.state[2:3]
+
+    def tick(self):
+        check(_abi.lib().dr_adam_tick_f32(_ptr(self.state), self.lr, self.beta1, self.beta2, _stream()),
+              "dr_adam_tick_f32")
 
 
 # ------------------------------------------------------------------ K1
@@ -230,13 +245,27 @@ def _check_pq(P, Q, u, ids):
     return B
 
 
-def bpr_step(P, Q, slotsP, slotsQ, u, i, j, opt, ws=None):
-    """One BPRMF.train_op (bprmf.py:114-123) in place; returns the device scalar sum_b -log sigmoid(x_b)."""
+def bpr_plan(num_user, num_item, k, u, i, j, ws):
+    """Build the id lists and segment plans of batch (u, i, j) into ws (for bpr_step(..., planned=True))."""
+    B = u.numel()
+    for name, t in (("u", u), ("i", i), ("j", j)):
+        if _i32(t, name).numel() != B:
+            raise ValueError("%s must have %d entries" % (name, B))
+    if ws.key[:4] != (B, int(k), int(num_user), int(num_item)):
+        raise ValueError("StepWorkspace was sized for %s" % (ws.key,))
+    check(_abi.lib().dr_bpr_plan_f32(num_user, num_item, k, _ptr(u), _ptr(i), _ptr(j), B, ws.key[4], _ptr(ws.buf),
+                                     ws.buf.numel(), _stream()), "dr_bpr_plan_f32")
+
+
+def bpr_step(P, Q, slotsP, slotsQ, u, i, j, opt, ws=None, planned=False):
+    """One BPRMF.train_op (bprmf.py:114-123) in place; returns the device scalar sum_b -log sigmoid(x_b).
+    planned=True: ws already holds bpr_plan() of the same batch."""
     B = _check_pq(P, Q, u, (("u", u), ("i", i), ("j", j)))
     _slots(opt, slotsP[0], slotsP[1], P, "bpr_step(P)")
     _slots(opt, slotsQ[0], slotsQ[1], Q, "bpr_step(Q)")
     ws = _step_ws(ws, B, P.shape[1], P.shape[0], Q.shape[0], opt, P.device)
-    check(_abi.lib().dr_bpr_step_f32(_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), P.shape[0], _ptr(Q), _ptr(slotsQ[0]),
+    fn = _abi.lib().dr_bpr_step_planned_f32 if planned else _abi.lib().dr_bpr_step_f32
+    check(fn(_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), P.shape[0], _ptr(Q), _ptr(slotsQ[0]),
                                      _ptr(slotsQ[1]), Q.shape[0], P.shape[1], _ptr(u), _ptr(i), _ptr(j), B,
                                      C.byref(opt), _ptr(ws.loss), _ptr(ws.buf), ws.buf.numel(), _stream()),
           "dr_bpr_step_f32")

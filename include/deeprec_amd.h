@@ -68,6 +68,9 @@ typedef struct dr_opt_params {
     float momentum;  /* RMSProp momentum                                       */
     float reg;       /* L2 coefficient (reg_rate)                              */
     int32_t reg_mode;/* DR_REG_*                                               */
+    const float* alpha_dev; /* optional DEVICE scalar overriding `alpha` (read by the kernels at run time), so a
+                               captured hipGraph of a step keeps following Adam's bias correction; see
+                               dr_adam_tick_f32.  NULL = use `alpha`.                                  */
 } dr_opt_params;
 
 const char* dr_last_error(void);
@@ -148,6 +151,19 @@ int32_t dr_bpr_step_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user
                         const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
                         const dr_opt_params* opt, float* loss_out, void* ws, int64_t ws_bytes,
                         void* stream);
+
+/* The same step split for input pipelines: the id lists and segment plans of a batch depend on its ids
+ * only (the reference builds the whole epoch's id lists up front, bprmf.py:126-140), so a host may build
+ * them for batch t+1 on another stream while step t runs.  dr_bpr_plan_f32 fills the plan part of `ws`;
+ * dr_bpr_step_planned_f32 is dr_bpr_step_f32 minus that work and must see the plan of the SAME (u, i, j). */
+int32_t dr_bpr_plan_f32(int64_t num_user, int64_t num_item, int32_t k, const int32_t* u, const int32_t* i,
+                        const int32_t* j, int64_t B, int32_t reg_mode, void* ws, int64_t ws_bytes,
+                        void* stream);
+int32_t dr_bpr_step_planned_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q,
+                                float* Qslot0, float* Qslot1, int64_t num_item, int32_t k,
+                                const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                                const dr_opt_params* opt, float* loss_out, void* ws, int64_t ws_bytes,
+                                void* stream);
 
 /* Forward only: x_ui - x_uj and -log(sigmoid) per sample (bprmf.py:84-92,118-119). */
 int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t num_user, int64_t num_item,
@@ -241,6 +257,10 @@ int32_t dr_score_matrix_f32(const float* U, const float* U2, int64_t Nu, const f
  * tf.random.normal at bprmf.py:75-76, whose RNG stream cannot be reproduced). */
 int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, float stddev, uint64_t offset,
                            void* stream);
+/* Device-side Adam step state, like TensorFlow's beta1_power / beta2_power variables ([TF-ext]
+ * AdamOptimizer._finish): state[0] *= beta1, state[1] *= beta2 (fp32 running products, initialise to 1),
+ * state[2] = lr * sqrt(1 - state[1]) / (1 - state[0]).  Point dr_opt_params.alpha_dev at &state[2]. */
+int32_t dr_adam_tick_f32(float* state, float lr, float beta1, float beta2, void* stream);
 /* Fixed-order sum of x[0..n) into out[0] (deterministic loss reduction). */
 int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream);
 
