@@ -22,11 +22,11 @@ struct PlanLayout {
     int64_t long_seg, long_cb, part_owner, partials, partial_rows, msrc, mcoef;
 };
 
-// Segments longer than LONG_SEG contributions are summed in two passes so that a popular row does not
-// serialise the launch: seg_long_partial_kernel gives every DR_SEG_CHUNK-block of every long segment its
+// Segments with more than LONG_SEG contributions ("long": anything beyond the few-duplicates common case) are
+// summed in two passes so that neither a popular row nor a moderately repeated one serialises the launch: seg_long_partial_kernel gives every DR_SEG_CHUNK-block of every long segment its
 // own sub-wave (block partials parked in the plan's scratch), seg_long_combine_kernel adds a segment's
 // partials in block order and applies the update -- the same blocked position order, in parallel.
-constexpr int LONG_SEG = 2 * DR_SEG_CHUNK;
+constexpr int LONG_SEG = 4;
 
 static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
     size_t t_sort = 0, t_scan = 0;
@@ -257,23 +257,23 @@ __global__ __launch_bounds__(256) void seg_meta_kernel(const int32_t* __restrict
 
 // sum of contributions [y0, y1) (one DR_SEG_CHUNK block) for vector column c, sequential in y;
 // the row loads of a block are independent of the running sum, so they are issued 8 at a time
-template <int V>
+template <int V, int UNR>
 __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int c, float (&acc)[V]) {
 #pragma unroll
     for (int x = 0; x < V; ++x) acc[x] = 0.0f;
     const float* __restrict__ src = a.src;
     int y = y0;
-    for (; y + 8 <= y1; y += 8) {
-        float v[8][V];
-        float cf[8];
-        int si[8];
+    for (; y + UNR <= y1; y += UNR) {
+        float v[UNR][V];
+        float cf[UNR];
+        int si[UNR];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < UNR; ++q) {
             si[q] = a.msrc[y + q];
             cf[q] = a.coef ? a.coef[a.spos[y + q] - a.pos_lo] : 1.0f;
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < UNR; ++q) {
             if (si[q] >= 0) {
                 vload<V>(v[q], src + (int64_t)si[q] * a.k + c * V);
             } else {
@@ -283,7 +283,7 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < UNR; ++q) {
 #pragma unroll
             for (int x = 0; x < V; ++x) acc[x] = acc[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
         }
@@ -350,7 +350,7 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, f
     vstore<V>(a.table + off, w);
 }
 
-// short segments: one sub-wave per segment
+// short segments (<= LONG_SEG contributions, the common case): one sub-wave per segment
 template <int V, int LPR>
 __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
     a.opt = resolve(a.opt);
@@ -365,9 +365,9 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
         if ((int64_t)r >= a.rows) continue;  // sentinel segment of out-of-range ids / the other table's rows
         const int b = a.seg_start[s], e = a.seg_start[s + 1];
         if (e - b > LONG_SEG) continue;      // seg_long_kernel's
-        if (e - b <= 4) {
-            // the common case (mostly unique ids): resolve the <= 4 contributions once, then every vector
-            // column issues its source-row and destination-row loads together (same blocked order: one block)
+        {
+            // resolve the <= 4 contributions once, then every vector column issues its source-row and
+            // destination-row loads together (blocked order: a single block)
             const int len = e - b;
             int64_t si[4];
             float cf[4];
@@ -397,18 +397,6 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
                 for (int x = 0; x < V; ++x) tot[x] = 0.0f + tot[x];
                 apply_row<V>(a, r, c, tot);
             }
-            continue;
-        }
-        for (int c = lane; c < cpr; c += LPR) {
-            float tot[V], acc[V];
-#pragma unroll
-            for (int x = 0; x < V; ++x) tot[x] = 0.0f;
-            for (int c0 = b; c0 < e; c0 += DR_SEG_CHUNK) {
-                block_sum<V>(a, c0, (c0 + DR_SEG_CHUNK < e) ? c0 + DR_SEG_CHUNK : e, c, acc);
-#pragma unroll
-                for (int x = 0; x < V; ++x) tot[x] = tot[x] + acc[x];
-            }
-            apply_row<V>(a, r, c, tot);
         }
     }
 }
@@ -431,7 +419,7 @@ __global__ __launch_bounds__(256) void seg_long_partial_kernel(SegArgs a) {
         const int c1 = (c0 + DR_SEG_CHUNK < e) ? c0 + DR_SEG_CHUNK : e;
         for (int c = lane; c < cpr; c += LPR) {
             float acc[V];
-            block_sum<V>(a, c0, c1, c, acc);
+            block_sum<V, 8>(a, c0, c1, c, acc);
             vstore<V>(a.partials + (int64_t)pr * a.k + c * V, acc);
         }
     }
