@@ -19,7 +19,7 @@ constexpr int TU = 64;   // users per block tile
 constexpr int TI = 64;   // items per tile step
 constexpr int KC = 128;  // k-chunk staged in LDS
 constexpr int LDK = KC + 1;
-constexpr int LDS_S = TI + 1;
+constexpr int LDS_S = TI + 4;  // score tile row stride: 16-byte aligned rows, conflict-free for both access patterns
 constexpr int MAXK_TOP = 100;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -62,7 +62,254 @@ __device__ __forceinline__ float score_epilogue(float acc, float cdot, const flo
     return s;
 }
 
-constexpr int TCAP = 1024;  // held-out items of one 64-user panel cached in LDS (more: read from global)
+constexpr int TCAP = 512;  // held-out items of one 64-user panel cached in LDS (more: read from global)
+
+// ---- selection state of one block (one 64-user panel over a range of item tiles) ----------------------
+// LDS layout after the operand tiles (float offsets; everything but the top-K lists at compile-time offsets)
+constexpr int SS_OFF = 0;                         // [TU][LDS_S] score tile
+constexpr int TAU_OFF = SS_OFF + TU * LDS_S;      // [TU] K-th best so far (NaN: list not full, +inf: no such user)
+constexpr int MASK_OFF = TAU_OFF + TU;            // [TU] u64: masked (train) items of this tile
+constexpr int CAND_OFF = MASK_OFF + 2 * TU;       // [TU] u64: columns that beat tau in this tile
+constexpr int TPTR_OFF = CAND_OFF + 2 * TU;       // [TU+1] panel-local target offsets (+1 pad)
+constexpr int TSC_OFF = TPTR_OFF + TU + 2;        // [TCAP] target scores
+constexpr int TID_OFF = TSC_OFF + TCAP;           // [TCAP] target item id, -1 = masked target
+constexpr int TCNT_OFF = TID_OFF + TCAP;          // [TCAP] rank counters
+constexpr int TOPV_OFF = TCNT_OFF + TCAP;         // [TU][K] scores, then [TU][K] item ids
+static_assert((MASK_OFF % 2) == 0 && (SS_OFF % 4) == 0, "LDS alignment");
+
+struct Sel {
+    float* base;
+    int cur, cur_end, nxt;      // train cursor of the row thread, next train item cached
+    int tg0, ntg;               // this panel's slice of the target CSR
+    bool tg_lds, rowthread;
+    __device__ __forceinline__ float* sS() const { return base + SS_OFF; }
+    __device__ __forceinline__ float* tau() const { return base + TAU_OFF; }
+    __device__ __forceinline__ unsigned long long* maskw() const { return (unsigned long long*)(base + MASK_OFF); }
+    __device__ __forceinline__ unsigned long long* candw() const { return (unsigned long long*)(base + CAND_OFF); }
+    __device__ __forceinline__ int* tptr() const { return (int*)(base + TPTR_OFF); }
+    __device__ __forceinline__ float* tsc() const { return base + TSC_OFF; }
+    __device__ __forceinline__ int* tidl() const { return (int*)(base + TID_OFF); }
+    __device__ __forceinline__ int* tcnt() const { return (int*)(base + TCNT_OFF); }
+    __device__ __forceinline__ float* topv() const { return base + TOPV_OFF; }
+    __device__ __forceinline__ int* topi(int K) const { return (int*)(base + TOPV_OFF + TU * K); }
+};
+
+__device__ __forceinline__ void sel_init(Sel& z, const ScoreArgs& a, int64_t u0, int t_begin, int tid) {
+    const int K = a.K;
+    const int64_t myu = u0 + tid;
+    z.rowthread = tid < TU && myu < a.Nu;
+    z.cur = 0;
+    z.cur_end = 0;
+    z.nxt = 0x7fffffff;
+    z.tg0 = 0;
+    z.ntg = 0;
+    z.tg_lds = false;
+    for (int e = tid; e < TU * K; e += 256) {
+        z.topv()[e] = -INFINITY;
+        z.topi(K)[e] = 0x7fffffff;
+    }
+    if (tid < TU) {
+        z.tau()[tid] = (myu < a.Nu) ? __builtin_nanf("") : INFINITY;
+        z.candw()[tid] = 0ull;
+        z.maskw()[tid] = 0ull;
+    }
+    if (z.rowthread && a.train_ptr) {
+        z.cur = a.train_ptr[myu];
+        z.cur_end = a.train_ptr[myu + 1];
+        const int first = t_begin * TI;
+        int lo = z.cur, hi = z.cur_end;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (a.train_idx[mid] < first) lo = mid + 1; else hi = mid;
+        }
+        z.cur = lo;
+        z.nxt = z.cur < z.cur_end ? a.train_idx[z.cur] : 0x7fffffff;
+    }
+    if (tid <= TU) z.tptr()[tid] = 0;
+    if (a.tgt_ptr) {
+        const int64_t ulast = (u0 + TU < a.Nu) ? u0 + TU : a.Nu;
+        z.tg0 = a.tgt_ptr[u0];
+        z.ntg = a.tgt_ptr[ulast] - z.tg0;
+        z.tg_lds = z.ntg <= TCAP;
+        if (tid <= TU) {
+            const int64_t u = (u0 + tid < a.Nu) ? u0 + tid : a.Nu;
+            z.tptr()[tid] = a.tgt_ptr[u] - z.tg0;
+        }
+        if (z.tg_lds)
+            for (int x = tid; x < z.ntg; x += 256) {
+                z.tsc()[x] = a.tgt_score[z.tg0 + x];
+                z.tidl()[x] = a.tgt_masked[z.tg0 + x] ? -1 : a.tgt_idx[z.tg0 + x];
+                z.tcnt()[x] = 0;
+            }
+    }
+}
+
+// row threads: train-item bitmap of the tile starting at item i0 (visible after the next barrier)
+__device__ __forceinline__ void sel_bitmap(Sel& z, const ScoreArgs& a, int64_t i0, int tid) {
+    if (!z.rowthread) return;
+    unsigned long long m = 0ull;
+    const int hi = (int)i0 + TI;
+    while (z.nxt < hi) {
+        m |= 1ull << (z.nxt - (int)i0);
+        ++z.cur;
+        z.nxt = z.cur < z.cur_end ? a.train_idx[z.cur] : 0x7fffffff;
+    }
+    z.maskw()[tid] = m;
+}
+
+// this lane's 16 uadd values (its rows are fixed for the whole item stream); -0.0f is the exact neutral element
+__device__ __forceinline__ void load_uadd(float (&ua)[16], const ScoreArgs& a, int64_t u0, int wu, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t u = u0 + wu * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        ua[r] = (a.uadd && u < a.Nu) ? a.uadd[u] : -0.0f;
+    }
+}
+__device__ __forceinline__ float load_iadd(const ScoreArgs& a, int64_t it) {
+    return (a.iadd && it < a.Ni) ? a.iadd[it] : -0.0f;
+}
+
+// 32x32 accumulator tile of wave (wu, wi) -> LDS score tile with the affine epilogue
+//   s = cdot * acc + uadd[u] + iadd[i];  ua[r] = uadd of this lane's r-th row, ia = iadd of its column.
+// Rows / columns beyond Nu / Ni hold don't-care values: the selection never looks at them.
+__device__ __forceinline__ void sel_store_scores(const Sel& z, const ScoreArgs& a, const f32x16& acc,
+                                                 const float (&ua)[16], float ia, bool affine, int wu, int wi,
+                                                 int lane) {
+    float* d = z.sS() + (wu * 32 + 4 * (lane >> 5)) * LDS_S + wi * 32 + (lane & 31);
+    if (affine) {
+        const float cd = a.cdot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = cd * acc[r];
+            s = s + ua[r];
+            s = s + ia;
+            d[((r & 3) + 8 * (r >> 2)) * LDS_S] = s;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2)) * LDS_S] = acc[r];
+    }
+}
+
+// the score tile is in sS (barrier before).  MATRIX: write it out.  Otherwise (row, quarter) threads run the
+// threshold filter for the top-K and the rank-of-target counting.  Common case first: no masked item in this
+// quarter and a full tile -> one group maximum against the K-th best, and a plain count of scores above the
+// target (ties and masked / ragged quarters take the exact per-score path).
+template <bool MATRIX>
+__device__ __forceinline__ void sel_filter(Sel& z, const ScoreArgs& a, int64_t u0, int64_t i0, int tid) {
+    if (MATRIX) {
+        for (int e = tid; e < TU * TI; e += 256) {
+            const int r = e / TI, c = e - r * TI;
+            const int64_t u = u0 + r, i = i0 + c;
+            if (u < a.Nu && i < a.Ni) {
+                float s = z.sS()[r * LDS_S + c];
+                if (a.act == 1) s = 1.0f / (1.0f + expf(-s));
+                a.out[u * a.Ni + i] = s;
+            }
+        }
+        return;
+    }
+    const int row = tid >> 2, q = tid & 3;
+    const float4* s4 = reinterpret_cast<const float4*>(z.sS() + row * LDS_S + q * 16);
+    float sv[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 v = s4[j];
+        sv[4 * j] = v.x; sv[4 * j + 1] = v.y; sv[4 * j + 2] = v.z; sv[4 * j + 3] = v.w;
+    }
+    const int nc = (a.Ni - i0 < TI) ? (int)(a.Ni - i0) : TI;
+    const unsigned mrow = reinterpret_cast<const unsigned short*>(z.maskw())[tid];  // bits q*16 .. q*16+15 of row
+    const float th = z.tau()[row];
+    const bool plain = (mrow == 0u) && (nc == TI);
+    unsigned live = 0xffffu;
+    if (!plain) {
+        live = 0u;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const bool ok = (q * 16 + c < nc) && !((mrow >> c) & 1u) && (sv[c] == sv[c]);
+            live |= ok ? (1u << c) : 0u;
+        }
+    }
+    float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sv[8], sv[9]), fmaxf(sv[10], sv[11])),
+                         fmaxf(fmaxf(sv[12], sv[13]), fmaxf(sv[14], sv[15]))));
+    if (!(mx <= th)) {  // also taken while the list is not full (th = NaN)
+        unsigned cand = 0u;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            cand |= (((live >> c) & 1u) && (sv[c] == sv[c]) && !(sv[c] <= th)) ? (1u << c) : 0u;
+        if (cand) atomicOr(&z.candw()[row], (unsigned long long)cand << (q * 16));
+    }
+    const int tb = z.tptr()[row], te = z.tptr()[row + 1];
+    for (int x = tb; x < te; ++x) {
+        const int ct = z.tg_lds ? z.tidl()[x] : (a.tgt_masked[z.tg0 + x] ? -1 : a.tgt_idx[z.tg0 + x]);
+        if (ct < 0) continue;
+        const float st = z.tg_lds ? z.tsc()[x] : a.tgt_score[z.tg0 + x];
+        int cnt = 0;
+        bool tie = false;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            cnt += (sv[c] > st) ? 1 : 0;
+            tie |= (sv[c] == st);
+        }
+        if (tie || !plain) {
+            const int item0 = (int)i0 + q * 16;
+            cnt = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) cnt += (((live >> c) & 1u) && beats(sv[c], item0 + c, st, ct)) ? 1 : 0;
+        }
+        if (cnt) {
+            if (z.tg_lds) atomicAdd(&z.tcnt()[x], cnt);
+            else atomicAdd(a.tgt_rank + z.tg0 + x, cnt);
+        }
+    }
+}
+
+// row threads: fold the candidates of the tile at i0 (score tile still in sS, barrier before) into the sorted list
+__device__ __forceinline__ void sel_fold(Sel& z, const ScoreArgs& a, int64_t i0, int tid) {
+    if (!z.rowthread) return;
+    unsigned long long m = z.candw()[tid];
+    if (!m) return;
+    const int K = a.K;
+    z.candw()[tid] = 0ull;
+    const float* srow = z.sS() + tid * LDS_S;
+    float* tv = z.topv() + tid * K;
+    int* ti = z.topi(K) + tid * K;
+    while (m) {
+        const int c = __builtin_ctzll(m);
+        m &= m - 1;
+        const float s = srow[c];
+        const int item = (int)(i0 + c);
+        if (beats(s, item, tv[K - 1], ti[K - 1])) {
+            int p = K - 1;
+            while (p > 0 && beats(s, item, tv[p - 1], ti[p - 1])) {
+                tv[p] = tv[p - 1];
+                ti[p] = ti[p - 1];
+                --p;
+            }
+            tv[p] = s;
+            ti[p] = item;
+        }
+    }
+    if (ti[K - 1] != 0x7fffffff) z.tau()[tid] = tv[K - 1];
+}
+
+__device__ __forceinline__ void sel_finish(const Sel& z, const ScoreArgs& a, int64_t u0, int split, int tid) {
+    const int K = a.K;
+    __syncthreads();
+    for (int e = tid; e < TU * K; e += 256) {
+        const int r = e / K, c = e - r * K;
+        const int64_t u = u0 + r;
+        if (u < a.Nu) {
+            const int64_t o = ((int64_t)split * a.Nu + u) * K + c;
+            a.part_v[o] = z.topv()[e];
+            a.part_i[o] = z.topi(K)[e];
+        }
+    }
+    if (a.tgt_ptr && z.tg_lds)
+        for (int x = tid; x < z.ntg; x += 256)
+            if (z.tcnt()[x]) atomicAdd(a.tgt_rank + z.tg0 + x, z.tcnt()[x]);
+}
 
 // Stage a [64 rows x kce] operand chunk into LDS (row stride LDK).  Global reads are float4 along k when
 // the row stride allows it; LDS writes are scalar because the padded stride breaks 16-byte alignment.
@@ -87,21 +334,14 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ dst, const float
     }
 }
 
+// ---- any k: user panel and item tile both staged through LDS in k-chunks (one block per CU) -----------
 template <bool MATRIX>
-__global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(256) void score_kernel_anyk(ScoreArgs a) {
     extern __shared__ __align__(16) float smem[];
     float* sU = smem;                // [TU][LDK]
     float* sI = sU + TU * LDK;       // [TI][LDK]
-    float* sS = sI + TI * LDK;       // [TU][LDS_S]
-    float* topv = sS + TU * LDS_S;   // [TU][K]
-    int* topi = (int*)(topv + TU * a.K);
-    float* tau = (float*)(topi + TU * a.K);                           // [TU] K-th best so far (NaN: list not full)
-    unsigned long long* maskw = (unsigned long long*)(tau + TU);      // [TU] masked (train) items of this tile
-    unsigned long long* candw = maskw + TU;                           // [TU] columns that beat tau in this tile
-    int* tptr = (int*)(candw + TU);                                   // [TU+1] panel-local target offsets
-    float* tsc_l = (float*)(tptr + TU + 1);                           // [TCAP]
-    int* tid_l = (int*)(tsc_l + TCAP);                                // [TCAP] item id, -1 = masked target
-    int* tcnt_l = tid_l + TCAP;                                       // [TCAP]
+    Sel z;
+    z.base = sI + TI * LDK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -111,68 +351,15 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
     const int t_begin = split * a.tiles_per_split;
     int t_end = t_begin + a.tiles_per_split;
     if (t_end > a.ntiles) t_end = a.ntiles;
-    const int K = a.K;
-
-    // ---- selection state -------------------------------------------------------------------
-    const int64_t myu = u0 + tid;
-    const bool rowthread = (!MATRIX) && tid < TU && myu < a.Nu;
-    int cur = 0, cur_end = 0, nxt = 0x7fffffff;   // train cursor of the row thread, next train item cached
-    int tg0 = 0, ntg = 0;                          // this panel's slice of the target CSR
-    bool tg_lds = false;
-    if (!MATRIX) {
-        for (int e = tid; e < TU * K; e += 256) {
-            topv[e] = -INFINITY;
-            topi[e] = 0x7fffffff;
-        }
-        if (tid < TU) {
-            tau[tid] = __builtin_nanf("");
-            candw[tid] = 0ull;
-            maskw[tid] = 0ull;
-        }
-        if (rowthread && a.train_ptr) {
-            cur = a.train_ptr[myu];
-            cur_end = a.train_ptr[myu + 1];
-            const int first = t_begin * TI;
-            int lo = cur, hi = cur_end;
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (a.train_idx[mid] < first) lo = mid + 1; else hi = mid;
-            }
-            cur = lo;
-            nxt = cur < cur_end ? a.train_idx[cur] : 0x7fffffff;
-        }
-        if (a.tgt_ptr) {
-            const int64_t ulast = (u0 + TU < a.Nu) ? u0 + TU : a.Nu;
-            tg0 = a.tgt_ptr[u0];
-            ntg = a.tgt_ptr[ulast] - tg0;
-            tg_lds = ntg <= TCAP;
-            if (tid <= TU) {
-                const int64_t u = (u0 + tid < a.Nu) ? u0 + tid : a.Nu;
-                tptr[tid] = a.tgt_ptr[u] - tg0;
-            }
-            if (tg_lds)
-                for (int x = tid; x < ntg; x += 256) {
-                    tsc_l[x] = a.tgt_score[tg0 + x];
-                    tid_l[x] = a.tgt_masked[tg0 + x] ? -1 : a.tgt_idx[tg0 + x];
-                    tcnt_l[x] = 0;
-                }
-        }
-    }
+    if (!MATRIX) sel_init(z, a, u0, t_begin, tid);
     const bool one_chunk = a.k <= KC;
+    const bool affine = a.uadd || a.iadd || a.cdot != 1.0f;
+    float ua[16];
+    load_uadd(ua, a, u0, wu, lane);
 
     for (int t = t_begin; t < t_end; ++t) {
         const int64_t i0 = (int64_t)t * TI;
-        // row threads: train-item bitmap of this tile (visible after the staging barrier below)
-        if (rowthread) {
-            unsigned long long m = 0ull;
-            const int hi = (int)i0 + TI;
-            while (nxt < hi) {
-                m |= 1ull << (nxt - (int)i0);
-                ++cur;
-                nxt = cur < cur_end ? a.train_idx[cur] : 0x7fffffff;
-            }
-            maskw[tid] = m;
-        }
+        if (!MATRIX) sel_bitmap(z, a, i0, tid);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -180,6 +367,7 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
             const int kcn = (a.k - kc0 < KC) ? (a.k - kc0) : KC;
             const int kce = (kcn + 1) & ~1;  // even, zero padded
             __syncthreads();
+            if (!MATRIX && kc0 == 0 && t > t_begin) sel_fold(z, a, i0 - TI, tid);
             if (!(one_chunk && t > t_begin))  // the user panel stays resident when k fits one chunk
                 stage_chunk(sU, a.U, u0, a.Nu, a.k, kc0, kcn, kce, tid);
             stage_chunk(sI, a.I, i0, a.Ni, a.k, kc0, kcn, kce, tid);
@@ -193,109 +381,174 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
                 for (int kk = 0; kk < kce; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
             }
         }
-        // accumulator -> LDS score tile with the affine epilogue
-        {
-            const int col = wi * 32 + (lane & 31);
-            const int64_t it = i0 + col;
+        sel_store_scores(z, a, acc, ua, load_iadd(a, i0 + wi * 32 + (lane & 31)), affine, wu, wi, lane);
+        __syncthreads();
+        sel_filter<MATRIX>(z, a, u0, i0, tid);
+    }
+    if (!MATRIX && t_begin < t_end) {
+        __syncthreads();
+        sel_fold(z, a, (int64_t)(t_end - 1) * TI, tid);
+    }
+    if (!MATRIX) sel_finish(z, a, u0, split, tid);
+}
+
+// ---- k <= 2*KS (the usual case): the block's user panel lives in REGISTERS as the MFMA A operand for the
+// whole item stream (lane l holds U[row l%32][2j + l/32], j < KS); only item tiles go through LDS, and the
+// next tile's global loads are issued before the MFMA loop of the current one.  LDS per block is small
+// enough for two blocks per CU, so one block's MFMA stream covers the other's staging and selection. ----
+//
+// Thread -> chunk element mapping, all compile-time: W floats per element (float4 when k % 4 == 0), CPT
+// elements per row (power of two covering the widest chunk of this instantiation), thread tid owns column
+// element tid % CPT of rows tid / CPT + q * RPP.  Global addresses are (uniform tile base) + (per-thread
+// constant 32-bit offset); LDS addresses are (per-thread constant) + immediates.
+template <int KS, bool VEC>
+struct Geo {
+    static constexpr int W = VEC ? 4 : 1;
+    static constexpr int CPT = VEC ? (KS >= 64 ? 32 : 16) : (KS >= 64 ? 128 : 64);
+    static constexpr int RPP = 256 / CPT;
+    static constexpr int PASSES = TI / RPP;
+    static constexpr int NPRE = PASSES * W;
+};
+
+template <int KS, bool VEC, int N>
+__device__ __forceinline__ void prefetch_chunk(float (&pre)[N], const float* __restrict__ I,
+                                               int64_t i0, int64_t Ni, int k, int kc0, int r0, int gc) {
+    using G = Geo<KS, VEC>;
+    const char* tile = reinterpret_cast<const char*>(I) + (i0 * k + kc0) * 4;  // block-uniform
+    if (i0 + TI <= Ni) {
+        const uint32_t voff = ((uint32_t)r0 * (uint32_t)k + (uint32_t)gc * G::W) * 4u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wu * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int64_t u = u0 + row;
-                float s = 0.0f;
-                if (u < a.Nu && it < a.Ni) s = score_epilogue(acc[r], a.cdot, a.uadd, a.iadd, u, it);
-                sS[row * LDS_S + col] = s;
+        for (int q = 0; q < G::PASSES; ++q) {
+            const char* p = tile + (int64_t)(q * G::RPP) * k * 4 + voff;
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4*>(p);
+                pre[4 * q] = v.x; pre[4 * q + 1] = v.y; pre[4 * q + 2] = v.z; pre[4 * q + 3] = v.w;
+            } else {
+                pre[q] = *reinterpret_cast<const float*>(p);
             }
         }
-        __syncthreads();
-        if (MATRIX) {
-            for (int e = tid; e < TU * TI; e += 256) {
-                const int r = e / TI, c = e - r * TI;
-                const int64_t u = u0 + r, i = i0 + c;
-                if (u < a.Nu && i < a.Ni) {
-                    float s = sS[r * LDS_S + c];
-                    if (a.act == 1) s = 1.0f / (1.0f + expf(-s));
-                    a.out[u * a.Ni + i] = s;
-                }
-            }
-        } else {
-            // (row, quarter) threads: threshold filter for the top-K and rank-of-target counting
-            const int row = tid >> 2, q = tid & 3;
-            const int64_t u = u0 + row;
-            if (u < a.Nu) {
-                const float* srow = sS + row * LDS_S + q * 16;
-                const int nc = (a.Ni - i0 < TI) ? (int)(a.Ni - i0) : TI;
-                unsigned live = 0u, cand = 0u;
-                const unsigned mrow = (unsigned)((maskw[row] >> (q * 16)) & 0xffffull);
-                const float th = tau[row];
-                float sv[16];
+    } else {  // ragged last tile: rows beyond Ni re-read the last valid row (their scores are never looked at)
+        const int rmax = (int)(Ni - 1 - i0);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    sv[c] = srow[c];
-                    const bool ok = (q * 16 + c < nc) && !((mrow >> c) & 1u) && (sv[c] == sv[c]);
-                    live |= ok ? (1u << c) : 0u;
-                    cand |= (ok && !(sv[c] <= th)) ? (1u << c) : 0u;
-                }
-                if (cand) atomicOr(&candw[row], (unsigned long long)cand << (q * 16));
-                const int tb = a.tgt_ptr ? tptr[row] : 0, te = a.tgt_ptr ? tptr[row + 1] : 0;
-                for (int x = tb; x < te; ++x) {
-                    const int ct = tg_lds ? tid_l[x] : (a.tgt_masked[tg0 + x] ? -1 : a.tgt_idx[tg0 + x]);
-                    if (ct < 0) continue;
-                    const float st = tg_lds ? tsc_l[x] : a.tgt_score[tg0 + x];
-                    const int item0 = (int)i0 + q * 16;
-                    int cnt = 0;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) cnt += (((live >> c) & 1u) && beats(sv[c], item0 + c, st, ct)) ? 1 : 0;
-                    if (cnt) {
-                        if (tg_lds) atomicAdd(&tcnt_l[x], cnt);
-                        else atomicAdd(a.tgt_rank + tg0 + x, cnt);
-                    }
-                }
-            }
-            __syncthreads();
-            // row threads: fold this tile's candidates into the sorted top-K list
-            if (rowthread) {
-                unsigned long long m = candw[tid];
-                if (m) {
-                    candw[tid] = 0ull;
-                    const float* srow = sS + tid * LDS_S;
-                    float* tv = topv + tid * K;
-                    int* ti = topi + tid * K;
-                    while (m) {
-                        const int c = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const float s = srow[c];
-                        const int item = (int)(i0 + c);
-                        if (beats(s, item, tv[K - 1], ti[K - 1])) {
-                            int p = K - 1;
-                            while (p > 0 && beats(s, item, tv[p - 1], ti[p - 1])) {
-                                tv[p] = tv[p - 1];
-                                ti[p] = ti[p - 1];
-                                --p;
-                            }
-                            tv[p] = s;
-                            ti[p] = item;
-                        }
-                    }
-                    if (ti[K - 1] != 0x7fffffff) tau[tid] = tv[K - 1];
-                }
+        for (int q = 0; q < G::PASSES; ++q) {
+            int r = r0 + q * G::RPP;
+            r = r < rmax ? r : rmax;
+            const char* p = tile + ((int64_t)r * k + gc * G::W) * 4;
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4*>(p);
+                pre[4 * q] = v.x; pre[4 * q + 1] = v.y; pre[4 * q + 2] = v.z; pre[4 * q + 3] = v.w;
+            } else {
+                pre[q] = *reinterpret_cast<const float*>(p);
             }
         }
     }
-    if (!MATRIX) {
-        __syncthreads();
-        for (int e = tid; e < TU * K; e += 256) {
-            const int r = e / K, c = e - r * K;
-            const int64_t u = u0 + r;
-            if (u < a.Nu) {
-                const int64_t o = ((int64_t)split * a.Nu + u) * K + c;
-                a.part_v[o] = topv[e];
-                a.part_i[o] = topi[e];
+}
+
+template <int KS, bool VEC, int N>
+__device__ __forceinline__ void store_chunk(float* __restrict__ d, const float (&pre)[N]) {
+    using G = Geo<KS, VEC>;
+#pragma unroll
+    for (int q = 0; q < G::PASSES; ++q) {
+#pragma unroll
+        for (int j = 0; j < G::W; ++j) d[q * G::RPP * LDK + j] = pre[q * G::W + j];
+    }
+}
+
+template <bool MATRIX, int KS, bool VEC>
+__global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
+    using G = Geo<KS, VEC>;
+    extern __shared__ __align__(16) float smem[];
+    float* sI = smem;  // [TI][LDK]
+    Sel z;
+    z.base = smem + TI * LDK;
+    constexpr int NCH = (2 * KS + KC - 1) / KC;      // item chunks per tile (compile-time upper bound)
+    constexpr int JPC = KS < KC / 2 ? KS : KC / 2;   // k-steps per chunk
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wu = wave >> 1, wi = wave & 1;
+    const int64_t u0 = (int64_t)blockIdx.x * TU;
+    const int split = blockIdx.y;
+    const int t_begin = split * a.tiles_per_split;
+    int t_end = t_begin + a.tiles_per_split;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    const int k = a.k;
+
+    // A operand: this lane's user row, k-steps 2j + (lane >> 5), zero beyond k / Nu
+    float areg[KS];
+    {
+        const int64_t urow = u0 + wu * 32 + (lane & 31);
+        const float* up = a.U + urow * k + (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) areg[j] = (urow < a.Nu && 2 * j + (lane >> 5) < k) ? up[2 * j] : 0.0f;
+    }
+    // columns that no chunk store touches must read as zero in the MFMA loop (groups of 16 k)
+    for (int e = tid; e < TI * LDK; e += 256) sI[e] = 0.0f;
+    if (!MATRIX) sel_init(z, a, u0, t_begin, tid);
+    const bool affine = a.uadd || a.iadd || a.cdot != 1.0f;
+    float ua[16];
+    load_uadd(ua, a, u0, wu, lane);
+    const int mycol = wi * 32 + (lane & 31);
+
+    // chunk geometry of this thread: chunk 0 is min(k, KC) wide, chunk 1 (k > KC) the rest
+    const int g = tid % G::CPT, r0 = tid / G::CPT;
+    const int kc_first = k < KC ? k : KC;
+    const bool live0 = g * G::W < kc_first;
+    const bool live1 = NCH > 1 && g * G::W < k - KC;
+    const int gc0 = live0 ? g : 0, gc1 = live1 ? g : 0;
+    float* dst = sI + r0 * LDK + g * G::W;
+    const float* pb = sI + mycol * LDK + (lane >> 5);
+
+    float pre[G::NPRE];
+    float ia_next = -0.0f;
+    if (t_begin < t_end) {
+        prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, (int64_t)t_begin * TI, a.Ni, k, 0, r0, gc0);
+        ia_next = load_iadd(a, (int64_t)t_begin * TI + mycol);
+    }
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int64_t i0 = (int64_t)t * TI;
+        if (!MATRIX) sel_bitmap(z, a, i0, tid);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float ia = ia_next;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int kc0 = c * KC;
+            if (kc0 < k) {  // block-uniform
+                const int kcn = (k - kc0 < KC) ? (k - kc0) : KC;
+                __syncthreads();  // every wave is done with the previous chunk in sI and has filtered sS
+                if (!MATRIX && c == 0 && t > t_begin) sel_fold(z, a, i0 - TI, tid);
+                if (c == 0 ? live0 : live1) store_chunk<KS, VEC, G::NPRE>(dst, pre);
+                __syncthreads();
+                // next chunk (this tile's or the next tile's first) -> registers, in flight during the MFMAs
+                if (kc0 + KC < k) {
+                    prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, i0, a.Ni, k, kc0 + KC, r0, gc1);
+                } else if (t + 1 < t_end) {
+                    prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, i0 + TI, a.Ni, k, 0, r0, gc0);
+                    ia_next = load_iadd(a, i0 + TI + mycol);
+                }
+#pragma unroll
+                for (int gq = 0; gq < JPC / 8; ++gq) {
+                    if (gq * 16 < kcn) {  // block-uniform: skip whole groups beyond k
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * (KC / 2) + gq * 8 + j],
+                                                                        pb[(gq * 8 + j) * 2], acc, 0, 0, 0);
+                    }
+                }
             }
         }
-        if (a.tgt_ptr && tg_lds)
-            for (int x = tid; x < ntg; x += 256)
-                if (tcnt_l[x]) atomicAdd(a.tgt_rank + tg0 + x, tcnt_l[x]);
+        sel_store_scores(z, a, acc, ua, ia, affine, wu, wi, lane);
+        __syncthreads();
+        sel_filter<MATRIX>(z, a, u0, i0, tid);
     }
+    if (!MATRIX && t_begin < t_end) {
+        __syncthreads();
+        sel_fold(z, a, (int64_t)(t_end - 1) * TI, tid);
+    }
+    if (!MATRIX) sel_finish(z, a, u0, split, tid);
 }
 
 // S-way merge of the per-split sorted candidate lists
@@ -541,10 +794,31 @@ static void topk_layout(int64_t Nu, int64_t Ni, int k, int K, int64_t ntgt, int 
     L->total = off;
 }
 
-static size_t score_smem_bytes(int K) {
-    return (size_t)(2 * TU * LDK + TU * LDS_S) * 4 + (size_t)TU * K * 8   // operands, score tile, top-K lists
-           + (size_t)TU * 4 + (size_t)TU * 16 + (size_t)(TU + 1) * 4 + 4    // tau, maskw + candw, tptr (+pad)
-           + (size_t)TCAP * 12;                                            // cached targets
+static size_t score_smem_bytes(int K, bool anyk) {
+    return ((size_t)(anyk ? 2 : 1) * TI * LDK + TOPV_OFF + (size_t)2 * TU * K) * 4;
+}
+
+template <bool MATRIX, int KS, bool VEC>
+static int launch_score_regs(const ScoreArgs& a, dim3 grid, hipStream_t st) {
+    const size_t smem = score_smem_bytes(a.K, false);
+    DR_HIP(hipFuncSetAttribute((const void*)score_kernel<MATRIX, KS, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    DR_LAUNCH((score_kernel<MATRIX, KS, VEC>), grid, dim3(256), smem, st, a);
+    DR_CHECK_LAUNCH("score_kernel");
+    return DR_OK;
+}
+
+template <bool MATRIX>
+static int launch_score(const ScoreArgs& a, dim3 grid, hipStream_t st) {
+    const bool vec = (a.k & 3) == 0;
+    if (a.k <= 64) return vec ? launch_score_regs<MATRIX, 32, true>(a, grid, st) : launch_score_regs<MATRIX, 32, false>(a, grid, st);
+    if (a.k <= 128) return vec ? launch_score_regs<MATRIX, 64, true>(a, grid, st) : launch_score_regs<MATRIX, 64, false>(a, grid, st);
+    if (a.k <= 256) return vec ? launch_score_regs<MATRIX, 128, true>(a, grid, st) : launch_score_regs<MATRIX, 128, false>(a, grid, st);
+    const size_t smem = score_smem_bytes(a.K, true);
+    DR_HIP(hipFuncSetAttribute((const void*)score_kernel_anyk<MATRIX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DR_LAUNCH((score_kernel_anyk<MATRIX>), grid, dim3(256), smem, st, a);
+    DR_CHECK_LAUNCH("score_kernel_anyk");
+    return DR_OK;
 }
 
 // Prepare (U', I', uadd, iadd, cdot) for a score kind.  Returns DR_OK / error.
@@ -656,12 +930,10 @@ extern "C" int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu
                            (float*)(base + L.tgt_score), (int32_t*)(base + L.tgt_masked), tgt_rank);
         DR_CHECK_LAUNCH("target_prologue_kernel");
     }
-    const size_t smem = score_smem_bytes(K);
-    DR_HIP(hipFuncSetAttribute((const void*)score_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int64_t panels = (Nu + TU - 1) / TU;
     DR_REQUIRE(panels < (1ll << 31), "dr_score_topk_f32: too many user panels");
-    DR_LAUNCH((score_kernel<false>), dim3((unsigned)panels, (unsigned)L.S), dim3(256), smem, st, a);
-    DR_CHECK_LAUNCH("score_kernel");
+    rc = launch_score<false>(a, dim3((unsigned)panels, (unsigned)L.S), st);
+    if (rc != DR_OK) return rc;
     DR_LAUNCH(topk_merge_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, a.part_v, a.part_i, L.S, Nu, K,
                        topk_idx, topk_score);
     DR_CHECK_LAUNCH("topk_merge_kernel");
@@ -707,11 +979,7 @@ extern "C" int32_t dr_score_matrix_f32(const float* U, const float* U2, int64_t 
     if (S > 65535) S = 65535;
     a.tiles_per_split = (L.ntiles + S - 1) / S;
     S = (L.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
-    const size_t smem = score_smem_bytes(1);
-    DR_HIP(hipFuncSetAttribute((const void*)score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DR_LAUNCH((score_kernel<true>), dim3((unsigned)panels, (unsigned)S), dim3(256), smem, st, a);
-    DR_CHECK_LAUNCH("score_kernel<matrix>");
-    return DR_OK;
+    return launch_score<true>(a, dim3((unsigned)panels, (unsigned)S), st);
 }
 
 extern "C" int32_t dr_topk_rank_f32(const float* scores, int64_t Nu, int64_t Ni, const int32_t* train_ptr,
