@@ -64,28 +64,28 @@ __device__ __forceinline__ float score_epilogue(float acc, float cdot, const flo
 
 constexpr int TCAP = 512;  // held-out items of one 64-user panel cached in LDS (more: read from global)
 
-// ---- selection state of one block (one 64-user panel over a range of item tiles) ----------------------
+// ---- selection state of one 256-thread group (one 64-user panel over a range of item tiles) -------------
+// Thread th of the group looks at row th/4, columns (th%4)*16 .. +15 of each 64x64 score tile; the four
+// threads of a row are adjacent lanes of one wave, and lane th%4 == 0 is the row's owner: it keeps the row's
+// train-CSR cursor and K-th best score in registers and maintains the row's sorted top-K list in LDS.
+// Quad-local exchange is DPP (no LDS, no barrier).
+//
 // LDS layout after the operand tiles (float offsets; everything but the top-K lists at compile-time offsets)
 constexpr int SS_OFF = 0;                         // [TU][LDS_S] score tile
-constexpr int TAU_OFF = SS_OFF + TU * LDS_S;      // [TU] K-th best so far (NaN: list not full, +inf: no such user)
-constexpr int MASK_OFF = TAU_OFF + TU;            // [TU] u64: masked (train) items of this tile
-constexpr int CAND_OFF = MASK_OFF + 2 * TU;       // [TU] u64: columns that beat tau in this tile
-constexpr int TPTR_OFF = CAND_OFF + 2 * TU;       // [TU+1] panel-local target offsets (+1 pad)
+constexpr int TPTR_OFF = SS_OFF + TU * LDS_S;     // [TU+1] panel-local target offsets (+1 pad)
 constexpr int TSC_OFF = TPTR_OFF + TU + 2;        // [TCAP] target scores
 constexpr int TID_OFF = TSC_OFF + TCAP;           // [TCAP] target item id, -1 = masked target
 constexpr int TCNT_OFF = TID_OFF + TCAP;          // [TCAP] rank counters
-constexpr int TOPV_OFF = TCNT_OFF + TCAP;         // [TU][K] scores, then [TU][K] item ids
-static_assert((MASK_OFF % 2) == 0 && (SS_OFF % 4) == 0, "LDS alignment");
+constexpr int TOPV_OFF = TCNT_OFF + TCAP + 2;     // [TU][K] scores, then [TU][K] item ids
+static_assert((SS_OFF % 4) == 0 && (TOPV_OFF % 4) == 0, "LDS alignment");
 
 struct Sel {
     float* base;
-    int cur, cur_end, nxt;      // train cursor of the row thread, next train item cached
-    int tg0, ntg;               // this panel's slice of the target CSR
-    bool tg_lds, rowthread;
+    int cur, cur_end, nxt, nxt2;  // row owner: train cursor, next two train items cached
+    float tau;                    // row owner: K-th best so far (NaN: list not full, +inf: no such user)
+    int tg0, ntg;                 // this panel's slice of the target CSR
+    bool tg_lds, owner;
     __device__ __forceinline__ float* sS() const { return base + SS_OFF; }
-    __device__ __forceinline__ float* tau() const { return base + TAU_OFF; }
-    __device__ __forceinline__ unsigned long long* maskw() const { return (unsigned long long*)(base + MASK_OFF); }
-    __device__ __forceinline__ unsigned long long* candw() const { return (unsigned long long*)(base + CAND_OFF); }
     __device__ __forceinline__ int* tptr() const { return (int*)(base + TPTR_OFF); }
     __device__ __forceinline__ float* tsc() const { return base + TSC_OFF; }
     __device__ __forceinline__ int* tidl() const { return (int*)(base + TID_OFF); }
@@ -94,26 +94,35 @@ struct Sel {
     __device__ __forceinline__ int* topi(int K) const { return (int*)(base + TOPV_OFF + TU * K); }
 };
 
-__device__ __forceinline__ void sel_init(Sel& z, const ScoreArgs& a, int64_t u0, int t_begin, int tid) {
+// DPP quad permutes: every lane reads lane (quad base + SRC) / lane ^ 1 / lane ^ 2 of its quad
+template <int SRC>
+__device__ __forceinline__ int quad_get(int v) {
+    return __builtin_amdgcn_mov_dpp(v, SRC * 0x55, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int quad_sum(int v) {
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    return v;
+}
+
+// th = thread index within the 256-thread group; a barrier must follow before the first sel_tile
+__device__ __forceinline__ void sel_init(Sel& z, const ScoreArgs& a, int64_t u0, int t_begin, int th) {
     const int K = a.K;
-    const int64_t myu = u0 + tid;
-    z.rowthread = tid < TU && myu < a.Nu;
+    const int64_t myu = u0 + (th >> 2);
+    z.owner = (th & 3) == 0 && myu < a.Nu;
     z.cur = 0;
     z.cur_end = 0;
     z.nxt = 0x7fffffff;
+    z.nxt2 = 0x7fffffff;
+    z.tau = (myu < a.Nu) ? __builtin_nanf("") : INFINITY;
     z.tg0 = 0;
     z.ntg = 0;
     z.tg_lds = false;
-    for (int e = tid; e < TU * K; e += 256) {
+    for (int e = th; e < TU * K; e += 256) {
         z.topv()[e] = -INFINITY;
         z.topi(K)[e] = 0x7fffffff;
     }
-    if (tid < TU) {
-        z.tau()[tid] = (myu < a.Nu) ? __builtin_nanf("") : INFINITY;
-        z.candw()[tid] = 0ull;
-        z.maskw()[tid] = 0ull;
-    }
-    if (z.rowthread && a.train_ptr) {
+    if (z.owner && a.train_ptr) {
         z.cur = a.train_ptr[myu];
         z.cur_end = a.train_ptr[myu + 1];
         const int first = t_begin * TI;
@@ -124,37 +133,26 @@ __device__ __forceinline__ void sel_init(Sel& z, const ScoreArgs& a, int64_t u0,
         }
         z.cur = lo;
         z.nxt = z.cur < z.cur_end ? a.train_idx[z.cur] : 0x7fffffff;
+        z.nxt2 = z.cur + 1 < z.cur_end ? a.train_idx[z.cur + 1] : 0x7fffffff;
     }
-    if (tid <= TU) z.tptr()[tid] = 0;
+    if (th <= TU) z.tptr()[th] = 0;
     if (a.tgt_ptr) {
         const int64_t ulast = (u0 + TU < a.Nu) ? u0 + TU : a.Nu;
-        z.tg0 = a.tgt_ptr[u0];
-        z.ntg = a.tgt_ptr[ulast] - z.tg0;
+        const int64_t ufirst = u0 < a.Nu ? u0 : a.Nu;
+        z.tg0 = a.tgt_ptr[ufirst];
+        z.ntg = a.tgt_ptr[ulast > ufirst ? ulast : ufirst] - z.tg0;
         z.tg_lds = z.ntg <= TCAP;
-        if (tid <= TU) {
-            const int64_t u = (u0 + tid < a.Nu) ? u0 + tid : a.Nu;
-            z.tptr()[tid] = a.tgt_ptr[u] - z.tg0;
+        if (th <= TU) {
+            const int64_t u = (u0 + th < a.Nu) ? u0 + th : a.Nu;
+            z.tptr()[th] = a.tgt_ptr[u] - z.tg0;
         }
         if (z.tg_lds)
-            for (int x = tid; x < z.ntg; x += 256) {
+            for (int x = th; x < z.ntg; x += 256) {
                 z.tsc()[x] = a.tgt_score[z.tg0 + x];
                 z.tidl()[x] = a.tgt_masked[z.tg0 + x] ? -1 : a.tgt_idx[z.tg0 + x];
                 z.tcnt()[x] = 0;
             }
     }
-}
-
-// row threads: train-item bitmap of the tile starting at item i0 (visible after the next barrier)
-__device__ __forceinline__ void sel_bitmap(Sel& z, const ScoreArgs& a, int64_t i0, int tid) {
-    if (!z.rowthread) return;
-    unsigned long long m = 0ull;
-    const int hi = (int)i0 + TI;
-    while (z.nxt < hi) {
-        m |= 1ull << (z.nxt - (int)i0);
-        ++z.cur;
-        z.nxt = z.cur < z.cur_end ? a.train_idx[z.cur] : 0x7fffffff;
-    }
-    z.maskw()[tid] = m;
 }
 
 // this lane's 16 uadd values (its rows are fixed for the whole item stream); -0.0f is the exact neutral element
@@ -191,14 +189,15 @@ __device__ __forceinline__ void sel_store_scores(const Sel& z, const ScoreArgs& 
     }
 }
 
-// the score tile is in sS (barrier before).  MATRIX: write it out.  Otherwise (row, quarter) threads run the
-// threshold filter for the top-K and the rank-of-target counting.  Common case first: no masked item in this
-// quarter and a full tile -> one group maximum against the K-th best, and a plain count of scores above the
-// target (ties and masked / ragged quarters take the exact per-score path).
-template <bool MATRIX>
-__device__ __forceinline__ void sel_filter(Sel& z, const ScoreArgs& a, int64_t u0, int64_t i0, int tid) {
+// The score tile of items [i0, i0+64) is in sS (barrier before).  MATRIX: write it out.  Otherwise the
+// threshold filter for the top-K, the rank-of-target counting and the fold into the row's sorted list.
+// Common case first: no masked item in this quarter and a full tile -> one group maximum against the K-th
+// best, and a plain count of scores above the target (ties and masked / ragged quarters take the exact
+// per-score path).  Must be called by whole waves (DPP).
+template <bool MATRIX, bool TG_LDS>
+__device__ __forceinline__ void sel_tile_impl(Sel& z, const ScoreArgs& a, int64_t u0, int64_t i0, int th) {
     if (MATRIX) {
-        for (int e = tid; e < TU * TI; e += 256) {
+        for (int e = th; e < TU * TI; e += 256) {
             const int r = e / TI, c = e - r * TI;
             const int64_t u = u0 + r, i = i0 + c;
             if (u < a.Nu && i < a.Ni) {
@@ -209,7 +208,7 @@ __device__ __forceinline__ void sel_filter(Sel& z, const ScoreArgs& a, int64_t u
         }
         return;
     }
-    const int row = tid >> 2, q = tid & 3;
+    const int row = th >> 2, q = th & 3;
     const float4* s4 = reinterpret_cast<const float4*>(z.sS() + row * LDS_S + q * 16);
     float sv[16];
 #pragma unroll
@@ -217,9 +216,32 @@ __device__ __forceinline__ void sel_filter(Sel& z, const ScoreArgs& a, int64_t u
         const float4 v = s4[j];
         sv[4 * j] = v.x; sv[4 * j + 1] = v.y; sv[4 * j + 2] = v.z; sv[4 * j + 3] = v.w;
     }
+    // row owner: train-item bitmap of this tile, then its state goes to the quad
+    unsigned mlo = 0u, mhi = 0u;
+    if (z.owner) {
+        // The item after next is always already loaded, so the usual single advance of a tile does not
+        // wait on memory (and not on the tile prefetch in flight); only a second advance in one tile does.
+        const int hi = (int)i0 + TI;
+        if (z.nxt < hi) {
+            int b = z.nxt - (int)i0;
+            if (b < 32) mlo |= 1u << b; else mhi |= 1u << (b - 32);
+            ++z.cur;
+            z.nxt = z.nxt2;
+            z.nxt2 = z.cur + 1 < z.cur_end ? a.train_idx[z.cur + 1] : 0x7fffffff;
+            while (z.nxt < hi) {
+                b = z.nxt - (int)i0;
+                if (b < 32) mlo |= 1u << b; else mhi |= 1u << (b - 32);
+                ++z.cur;
+                z.nxt = z.nxt2;
+                z.nxt2 = z.cur + 1 < z.cur_end ? a.train_idx[z.cur + 1] : 0x7fffffff;
+            }
+        }
+    }
+    const unsigned qlo = (unsigned)quad_get<0>((int)mlo), qhi = (unsigned)quad_get<0>((int)mhi);  // all lanes active
+    const unsigned wsel = (q & 2) ? qhi : qlo;
+    const unsigned mrow = (wsel >> ((q & 1) * 16)) & 0xffffu;
+    const float th_k = __int_as_float(quad_get<0>(__float_as_int(z.tau)));
     const int nc = (a.Ni - i0 < TI) ? (int)(a.Ni - i0) : TI;
-    const unsigned mrow = reinterpret_cast<const unsigned short*>(z.maskw())[tid];  // bits q*16 .. q*16+15 of row
-    const float th = z.tau()[row];
     const bool plain = (mrow == 0u) && (nc == TI);
     unsigned live = 0xffffu;
     if (!plain) {
@@ -233,18 +255,18 @@ __device__ __forceinline__ void sel_filter(Sel& z, const ScoreArgs& a, int64_t u
     float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sv[8], sv[9]), fmaxf(sv[10], sv[11])),
                          fmaxf(fmaxf(sv[12], sv[13]), fmaxf(sv[14], sv[15]))));
-    if (!(mx <= th)) {  // also taken while the list is not full (th = NaN)
-        unsigned cand = 0u;
+    unsigned cand = 0u;
+    if (!(mx <= th_k)) {  // also taken while the list is not full (th_k = NaN)
 #pragma unroll
         for (int c = 0; c < 16; ++c)
-            cand |= (((live >> c) & 1u) && (sv[c] == sv[c]) && !(sv[c] <= th)) ? (1u << c) : 0u;
-        if (cand) atomicOr(&z.candw()[row], (unsigned long long)cand << (q * 16));
+            cand |= (((live >> c) & 1u) && (sv[c] == sv[c]) && !(sv[c] <= th_k)) ? (1u << c) : 0u;
     }
+    // rank-of-target counting: the quad's four partial counts are summed and the owner adds them up
     const int tb = z.tptr()[row], te = z.tptr()[row + 1];
-    for (int x = tb; x < te; ++x) {
-        const int ct = z.tg_lds ? z.tidl()[x] : (a.tgt_masked[z.tg0 + x] ? -1 : a.tgt_idx[z.tg0 + x]);
+    for (int x = tb; x < te; ++x) {  // same trip count on the four lanes of a row
+        const int ct = TG_LDS ? z.tidl()[x] : (a.tgt_masked[z.tg0 + x] ? -1 : a.tgt_idx[z.tg0 + x]);
         if (ct < 0) continue;
-        const float st = z.tg_lds ? z.tsc()[x] : a.tgt_score[z.tg0 + x];
+        const float st = TG_LDS ? z.tsc()[x] : a.tgt_score[z.tg0 + x];
         int cnt = 0;
         bool tie = false;
 #pragma unroll
@@ -258,46 +280,55 @@ __device__ __forceinline__ void sel_filter(Sel& z, const ScoreArgs& a, int64_t u
 #pragma unroll
             for (int c = 0; c < 16; ++c) cnt += (((live >> c) & 1u) && beats(sv[c], item0 + c, st, ct)) ? 1 : 0;
         }
-        if (cnt) {
-            if (z.tg_lds) atomicAdd(&z.tcnt()[x], cnt);
+        cnt = quad_sum(cnt);
+        if (q == 0 && cnt) {
+            if (TG_LDS) z.tcnt()[x] += cnt;  // only this lane ever touches entry x
             else atomicAdd(a.tgt_rank + z.tg0 + x, cnt);
         }
     }
-}
-
-// row threads: fold the candidates of the tile at i0 (score tile still in sS, barrier before) into the sorted list
-__device__ __forceinline__ void sel_fold(Sel& z, const ScoreArgs& a, int64_t i0, int tid) {
-    if (!z.rowthread) return;
-    unsigned long long m = z.candw()[tid];
-    if (!m) return;
-    const int K = a.K;
-    z.candw()[tid] = 0ull;
-    const float* srow = z.sS() + tid * LDS_S;
-    float* tv = z.topv() + tid * K;
-    int* ti = z.topi(K) + tid * K;
-    while (m) {
-        const int c = __builtin_ctzll(m);
-        m &= m - 1;
-        const float s = srow[c];
-        const int item = (int)(i0 + c);
-        if (beats(s, item, tv[K - 1], ti[K - 1])) {
-            int p = K - 1;
-            while (p > 0 && beats(s, item, tv[p - 1], ti[p - 1])) {
-                tv[p] = tv[p - 1];
-                ti[p] = ti[p - 1];
-                --p;
+    // candidates of the row -> its owner, which folds them into the sorted top-K list
+    const unsigned c1 = (unsigned)quad_get<1>((int)cand), c2 = (unsigned)quad_get<2>((int)cand),
+                   c3 = (unsigned)quad_get<3>((int)cand);
+    if (z.owner) {
+        unsigned long long m = (unsigned long long)(cand | (c1 << 16)) | ((unsigned long long)(c2 | (c3 << 16)) << 32);
+        if (m) {
+            const int K = a.K;
+            const float* srow = z.sS() + row * LDS_S;
+            float* tv = z.topv() + row * K;
+            int* ti = z.topi(K) + row * K;
+            while (m) {
+                const int c = __builtin_ctzll(m);
+                m &= m - 1;
+                const float s = srow[c];
+                const int item = (int)(i0 + c);
+                if (beats(s, item, tv[K - 1], ti[K - 1])) {
+                    int p = K - 1;
+                    while (p > 0 && beats(s, item, tv[p - 1], ti[p - 1])) {
+                        tv[p] = tv[p - 1];
+                        ti[p] = ti[p - 1];
+                        --p;
+                    }
+                    tv[p] = s;
+                    ti[p] = item;
+                }
             }
-            tv[p] = s;
-            ti[p] = item;
+            if (ti[K - 1] != 0x7fffffff) z.tau = tv[K - 1];
         }
     }
-    if (ti[K - 1] != 0x7fffffff) z.tau()[tid] = tv[K - 1];
 }
 
-__device__ __forceinline__ void sel_finish(const Sel& z, const ScoreArgs& a, int64_t u0, int split, int tid) {
+// two instantiations, so that the usual one (targets cached in LDS) has no global access in its target loop:
+// a wait on one would also wait for the item-tile prefetch in flight
+template <bool MATRIX>
+__device__ __forceinline__ void sel_tile(Sel& z, const ScoreArgs& a, int64_t u0, int64_t i0, int th) {
+    if (MATRIX || z.tg_lds) sel_tile_impl<MATRIX, true>(z, a, u0, i0, th);
+    else sel_tile_impl<MATRIX, false>(z, a, u0, i0, th);
+}
+
+// a barrier must precede (top-K lists and counters are written by other threads of the group)
+__device__ __forceinline__ void sel_finish(const Sel& z, const ScoreArgs& a, int64_t u0, int split, int th) {
     const int K = a.K;
-    __syncthreads();
-    for (int e = tid; e < TU * K; e += 256) {
+    for (int e = th; e < TU * K; e += 256) {
         const int r = e / K, c = e - r * K;
         const int64_t u = u0 + r;
         if (u < a.Nu) {
@@ -307,7 +338,7 @@ __device__ __forceinline__ void sel_finish(const Sel& z, const ScoreArgs& a, int
         }
     }
     if (a.tgt_ptr && z.tg_lds)
-        for (int x = tid; x < z.ntg; x += 256)
+        for (int x = th; x < z.ntg; x += 256)
             if (z.tcnt()[x]) atomicAdd(a.tgt_rank + z.tg0 + x, z.tcnt()[x]);
 }
 
@@ -359,7 +390,6 @@ __global__ __launch_bounds__(256) void score_kernel_anyk(ScoreArgs a) {
 
     for (int t = t_begin; t < t_end; ++t) {
         const int64_t i0 = (int64_t)t * TI;
-        if (!MATRIX) sel_bitmap(z, a, i0, tid);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -367,7 +397,6 @@ __global__ __launch_bounds__(256) void score_kernel_anyk(ScoreArgs a) {
             const int kcn = (a.k - kc0 < KC) ? (a.k - kc0) : KC;
             const int kce = (kcn + 1) & ~1;  // even, zero padded
             __syncthreads();
-            if (!MATRIX && kc0 == 0 && t > t_begin) sel_fold(z, a, i0 - TI, tid);
             if (!(one_chunk && t > t_begin))  // the user panel stays resident when k fits one chunk
                 stage_chunk(sU, a.U, u0, a.Nu, a.k, kc0, kcn, kce, tid);
             stage_chunk(sI, a.I, i0, a.Ni, a.k, kc0, kcn, kce, tid);
@@ -383,23 +412,21 @@ __global__ __launch_bounds__(256) void score_kernel_anyk(ScoreArgs a) {
         }
         sel_store_scores(z, a, acc, ua, load_iadd(a, i0 + wi * 32 + (lane & 31)), affine, wu, wi, lane);
         __syncthreads();
-        sel_filter<MATRIX>(z, a, u0, i0, tid);
+        sel_tile<MATRIX>(z, a, u0, i0, tid);  // the next write of sS is two barriers away
     }
-    if (!MATRIX && t_begin < t_end) {
+    if (!MATRIX) {
         __syncthreads();
-        sel_fold(z, a, (int64_t)(t_end - 1) * TI, tid);
+        sel_finish(z, a, u0, split, tid);
     }
-    if (!MATRIX) sel_finish(z, a, u0, split, tid);
 }
 
-// ---- k <= 2*KS (the usual case): the block's user panel lives in REGISTERS as the MFMA A operand for the
+// ---- k <= 2*KS (the usual case): a group's user panel lives in REGISTERS as the MFMA A operand for the
 // whole item stream (lane l holds U[row l%32][2j + l/32], j < KS); only item tiles go through LDS, and the
-// next tile's global loads are issued before the MFMA loop of the current one.  LDS per block is small
-// enough for two blocks per CU, so one block's MFMA stream covers the other's staging and selection. ----
+// next tile's global loads are issued a whole phase before they are needed. ----
 //
 // Thread -> chunk element mapping, all compile-time: W floats per element (float4 when k % 4 == 0), CPT
-// elements per row (power of two covering the widest chunk of this instantiation), thread tid owns column
-// element tid % CPT of rows tid / CPT + q * RPP.  Global addresses are (uniform tile base) + (per-thread
+// elements per row (power of two covering the widest chunk of this instantiation), thread th owns column
+// element th % CPT of rows th / CPT + q * RPP.  Global addresses are (uniform tile base) + (per-thread
 // constant 32-bit offset); LDS addresses are (per-thread constant) + immediates.
 template <int KS, bool VEC>
 struct Geo {
@@ -411,10 +438,10 @@ struct Geo {
 };
 
 template <int KS, bool VEC, int N>
-__device__ __forceinline__ void prefetch_chunk(float (&pre)[N], const float* __restrict__ I,
-                                               int64_t i0, int64_t Ni, int k, int kc0, int r0, int gc) {
+__device__ __forceinline__ void prefetch_chunk(float (&pre)[N], const float* __restrict__ I, int64_t i0, int64_t Ni,
+                                               int k, int kc0, int r0, int gc) {
     using G = Geo<KS, VEC>;
-    const char* tile = reinterpret_cast<const char*>(I) + (i0 * k + kc0) * 4;  // block-uniform
+    const char* tile = reinterpret_cast<const char*>(I) + (i0 * k + kc0) * 4;  // uniform
     if (i0 + TI <= Ni) {
         const uint32_t voff = ((uint32_t)r0 * (uint32_t)k + (uint32_t)gc * G::W) * 4u;
 #pragma unroll
@@ -454,6 +481,52 @@ __device__ __forceinline__ void store_chunk(float* __restrict__ d, const float (
     }
 }
 
+// 8 * NG MFMAs of one k-chunk: B operands come from LDS in groups of 8 k-steps, each group's reads issued one
+// group ahead of its MFMAs.  ng = number of groups that hold data (the rest of the chunk is skipped).
+template <int NG>
+__device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const float* __restrict__ pb, int ng) {
+    float b[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[0][j] = pb[2 * j];
+    if (ng == NG) {  // full chunk: one straight-line block
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[(gq + 1) & 1][j] = pb[((gq + 1) * 8 + j) * 2];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[gq * 8 + j], b[gq & 1][j], acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq < ng) {  // uniform
+                if (gq + 1 < NG) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[(gq + 1) & 1][j] = pb[((gq + 1) * 8 + j) * 2];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[gq * 8 + j], b[gq & 1][j], acc, 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void load_areg(float (&areg)[KS], const ScoreArgs& a, int64_t u0, int wu, int lane) {
+    const int64_t urow = u0 + wu * 32 + (lane & 31);
+    const float* up = a.U + urow * a.k + (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < KS; ++j) areg[j] = (urow < a.Nu && 2 * j + (lane >> 5) < a.k) ? up[2 * j] : 0.0f;
+}
+
+// Up to two k-chunks per tile (k <= 256).  LDS per block is small enough for two blocks per CU (K <= ~15), so
+// one block's MFMA stream covers the other's staging and selection stalls.  fp32 MFMA shares the SIMD's vector
+// pipe with ordinary VALU work (measured: a barrier-locked two-group ping-pong form ran no faster), so what
+// counts is the number of non-MFMA instructions per tile.
 template <bool MATRIX, int KS, bool VEC>
 __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
     using G = Geo<KS, VEC>;
@@ -474,14 +547,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
     if (t_end > a.ntiles) t_end = a.ntiles;
     const int k = a.k;
 
-    // A operand: this lane's user row, k-steps 2j + (lane >> 5), zero beyond k / Nu
     float areg[KS];
-    {
-        const int64_t urow = u0 + wu * 32 + (lane & 31);
-        const float* up = a.U + urow * k + (lane >> 5);
-#pragma unroll
-        for (int j = 0; j < KS; ++j) areg[j] = (urow < a.Nu && 2 * j + (lane >> 5) < k) ? up[2 * j] : 0.0f;
-    }
+    load_areg<KS>(areg, a, u0, wu, lane);
     // columns that no chunk store touches must read as zero in the MFMA loop (groups of 16 k)
     for (int e = tid; e < TI * LDK; e += 256) sI[e] = 0.0f;
     if (!MATRIX) sel_init(z, a, u0, t_begin, tid);
@@ -505,10 +572,12 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
         prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, (int64_t)t_begin * TI, a.Ni, k, 0, r0, gc0);
         ia_next = load_iadd(a, (int64_t)t_begin * TI + mycol);
     }
+    // every prologue load has landed: inside the loop only the tile prefetch is ever outstanding, so no wait
+    // in the loop body is inherited from the prologue
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
     for (int t = t_begin; t < t_end; ++t) {
         const int64_t i0 = (int64_t)t * TI;
-        if (!MATRIX) sel_bitmap(z, a, i0, tid);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -518,8 +587,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
             const int kc0 = c * KC;
             if (kc0 < k) {  // block-uniform
                 const int kcn = (k - kc0 < KC) ? (k - kc0) : KC;
-                __syncthreads();  // every wave is done with the previous chunk in sI and has filtered sS
-                if (!MATRIX && c == 0 && t > t_begin) sel_fold(z, a, i0 - TI, tid);
+                __syncthreads();  // every wave is done with the previous chunk in sI
                 if (c == 0 ? live0 : live1) store_chunk<KS, VEC, G::NPRE>(dst, pre);
                 __syncthreads();
                 // next chunk (this tile's or the next tile's first) -> registers, in flight during the MFMAs
@@ -529,26 +597,17 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
                     prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, i0 + TI, a.Ni, k, 0, r0, gc0);
                     ia_next = load_iadd(a, i0 + TI + mycol);
                 }
-#pragma unroll
-                for (int gq = 0; gq < JPC / 8; ++gq) {
-                    if (gq * 16 < kcn) {  // block-uniform: skip whole groups beyond k
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c * (KC / 2) + gq * 8 + j],
-                                                                        pb[(gq * 8 + j) * 2], acc, 0, 0, 0);
-                    }
-                }
+                mfma_chunk<JPC / 8>(acc, areg + c * (KC / 2), pb, (kcn + 15) >> 4);
             }
         }
         sel_store_scores(z, a, acc, ua, ia, affine, wu, wi, lane);
         __syncthreads();
-        sel_filter<MATRIX>(z, a, u0, i0, tid);
+        sel_tile<MATRIX>(z, a, u0, i0, tid);  // the next write of sS is two barriers away
     }
-    if (!MATRIX && t_begin < t_end) {
+    if (!MATRIX) {
         __syncthreads();
-        sel_fold(z, a, (int64_t)(t_end - 1) * TI, tid);
+        sel_finish(z, a, u0, split, tid);
     }
-    if (!MATRIX) sel_finish(z, a, u0, split, tid);
 }
 
 // S-way merge of the per-split sorted candidate lists
@@ -794,8 +853,9 @@ static void topk_layout(int64_t Nu, int64_t Ni, int k, int K, int64_t ntgt, int 
     L->total = off;
 }
 
+static size_t sel_area_floats(int K) { return (size_t)TOPV_OFF + (size_t)2 * TU * K; }
 static size_t score_smem_bytes(int K, bool anyk) {
-    return ((size_t)(anyk ? 2 : 1) * TI * LDK + TOPV_OFF + (size_t)2 * TU * K) * 4;
+    return ((size_t)(anyk ? 2 : 1) * TI * LDK + sel_area_floats(K)) * 4;
 }
 
 template <bool MATRIX, int KS, bool VEC>
@@ -808,6 +868,7 @@ static int launch_score_regs(const ScoreArgs& a, dim3 grid, hipStream_t st) {
     return DR_OK;
 }
 
+// grid = (64-user panels, item splits)
 template <bool MATRIX>
 static int launch_score(const ScoreArgs& a, dim3 grid, hipStream_t st) {
     const bool vec = (a.k & 3) == 0;

@@ -425,12 +425,15 @@ def _check_selection(scores, train, tgt, K_, idx, val, rank):
             off += len(tgt[u])
 
 
-@pytest.mark.parametrize("Nu,Ni,k,K_", [(942, 1682, 30, 10), (130, 3706, 64, 10), (65, 700, 150, 50), (3, 17, 1, 5),
-                                        (257, 129, 129, 10)])
-def test_score_topk_dot_exact(dev, Nu, Ni, k, K_):
+@pytest.mark.parametrize("Nu,Ni,k,K_,ntgt", [(942, 1682, 30, 10, 4), (130, 3706, 64, 10, 4), (65, 700, 150, 50, 4),
+                                             (3, 17, 1, 5, 4), (257, 129, 129, 10, 4), (200, 5000, 128, 10, 4),
+                                             (70, 1000, 200, 100, 4), (150, 2100, 256, 10, 24), (90, 1500, 300, 20, 4)])
+def test_score_topk_dot_exact(dev, Nu, Ni, k, K_, ntgt):
+    """k covers every kernel form (registers k<=64 / <=128 / <=256 with and without float4 rows, any-k), K the
+    one- and two-blocks-per-CU LDS budgets, ntgt=24 the panels whose held-out items do not fit the LDS cache."""
     from deeprec_amd import kernels as K
     rng = np.random.default_rng(Nu + Ni)
-    U, I, train, tgt = _eval_case(rng, Nu, Ni, k, min(40, Ni // 3), 4)
+    U, I, train, tgt = _eval_case(rng, Nu, Ni, k, min(40, Ni // 3), ntgt)
     tp, ti = _csr(train)
     gp, gi = _csr(tgt)
     idx, val, rank = K.score_topk(T(U, dev), T(I, dev), K_, train=(T(tp, dev), T(ti, dev)), targets=(T(gp, dev), T(gi, dev)))

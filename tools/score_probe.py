@@ -26,14 +26,14 @@ def main():
 
 def prof():
     dev = torch.device("cuda:0")
-    buf = torch.zeros(64, dtype=torch.int64, device=dev)
+    buf = torch.zeros(128, dtype=torch.int64, device=dev)
     os.environ["DR_SCORE_PROF"] = str(buf.data_ptr())
     main()
     torch.cuda.synchronize()
-    b = buf.cpu().numpy()[:40].reshape(4, 10)
-    names = ["fold+loop", "barA", "store", "barB", "pf+mfma", "sS", "barC", "sel_tile", "-", "-"]
+    b = buf.cpu().numpy()[:80].reshape(8, 10)
+    names = ["loop", "store", "prefetch", "sel_tile", "barSel", "mfma", "sS", "barCmp", "-", "-"]
     ntile = 3907
-    for w in range(4):
+    for w in range(8):
         print("wave", w, " ".join("%s=%d" % (n, b[w][i] // ntile) for i, n in enumerate(names) if n != "-"), "total", b[w].sum() // ntile)
 
 if os.environ.get("PROF"):
