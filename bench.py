@@ -225,7 +225,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_extras:
-        result.update(extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step))
+        result.update(extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step, eager_step))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
@@ -235,46 +235,112 @@ def main():
         dist.destroy_process_group()
 
 
-def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step):
+ROCPROF_NAMES = {   # live name -> kernel name in `rocprofv3 --kernel-trace --stats` output (k=128: V=4, 32 lanes/row)
+    "bpr_forward_kernel": "dr::bpr_forward_kernel<4, 32>",
+    "seg_update_kernel<item side>": "dr::seg_update_kernel<4, 32, 2>",
+    "seg_update_kernel<user side>": "dr::seg_update_kernel<4, 32, 1>",
+    "seg_long_partial_kernel": "dr::seg_long_partial_kernel<4, 32>",
+    "seg_long_combine_kernel": "dr::seg_long_combine_kernel<4, 32>",
+}
+LONG_SEG = 4        # deeprec_amd/csrc/segment.hip: segments with more contributions take the two-pass path
+SEG_CHUNK = 32      # DR_SEG_CHUNK
+
+
+def segment_census(ids):
+    """(short rows, short contributions, long rows, long contributions, partial rows) of one id list."""
+    cnt = torch.unique(ids, return_counts=True)[1]
+    short = cnt <= LONG_SEG
+    lc = cnt[~short]
+    return (int(short.sum()), int(cnt[short].sum()), int(lc.numel()), int(lc.sum()),
+            int(((lc + SEG_CHUNK - 1) // SEG_CHUNK).sum()))
+
+
+def live_kernel_profile(K, run_step, n_steps):
+    """Per-kernel durations of the step AS THE BENCH RUNS IT, from HIP events recorded by the library around each
+    launch on the stream it is launched on (dr_profile_enable / dr_profile_collect)."""
+    import ctypes as C
+    from deeprec_amd import _abi
+    lib = _abi.lib()
+    for t in range(4):
+        run_step(t)
+    torch.cuda.synchronize()
+    lib.dr_profile_enable(1)
+    for t in range(n_steps):
+        run_step(4 + t)
+    torch.cuda.synchronize()
+    lib.dr_profile_enable(0)
+    cap = 4096
+    names = C.create_string_buffer(1 << 18)
+    ms = (C.c_float * cap)()
+    n = lib.dr_profile_collect(names, len(names), ms, cap)
+    if n < 0:
+        raise RuntimeError("dr_profile_collect failed")
+    acc = {}
+    for nm, t in zip(names.value.decode().split("\n")[:n], list(ms)[:n]):
+        acc.setdefault(nm, []).append(t)
+    return acc
+
+
+def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step, eager_step):
     """Per-kernel rooflines (HIP events on the launch stream), standalone gather GB/s, eval users/s."""
     k, B = args.k, args.batch
     adam = args.opt == "adam"
     u, i, j = batches[0]
-    opt = opt_for(1)
     rows_rw = 6 if adam else 2            # (w[,m,v]) read + written per updated row
-    out = {}
-    # --- the kernels of one step, timed one by one --------------------------------------
-    g, loss_b, stash = K.bpr_forward(P, Q, u, i, j)
-    t_fwd = ev_time(lambda: K.bpr_forward(P, Q, u, i, j), 20, stream)
-    idsQ = torch.cat((i, j)).contiguous()
-    coefQ = torch.cat((g, -g)).contiguous()
-    srcQ = torch.cat((u, u)).contiguous()
-    planQ = K.SegmentPlan(idsQ, args.items)
-    planP = K.SegmentPlan(u, args.users)
-    t_planQ = ev_time(lambda: K.SegmentPlan(idsQ, args.items, planQ.ws), 20, stream)
-    t_planP = ev_time(lambda: K.SegmentPlan(u, args.users, planP.ws), 20, stream)
-    nsegQ = int(planQ.view()[1].numel())
-    nsegP = int(planP.view()[1].numel())
-    t_updQ = ev_time(lambda: K.sparse_row_update(Q, sQ[0], sQ[1], idsQ, P, opt, srcQ, coefQ, planQ), 20, stream)
-    t_updP = ev_time(lambda: K.sparse_row_update(P, sP[0], sP[1], u, stash, opt, None, None, planP), 20, stream)
     row = 4 * k
-    bytes_fwd = B * (12 + 3 * row + row + 8)                          # 3 ids, 3 rows read; stash row, g, loss written
-    bytes_updQ = 2 * B * (12 + row) + nsegQ * (rows_rw * row + 8)      # pos,src_idx,coef + src row per contribution
-    bytes_updP = B * (4 + row) + nsegP * (rows_rw * row + 8)
-    kern = {
-        "bpr_forward_kernel": (t_fwd, bytes_fwd),
-        "seg_update_kernel[Q]": (t_updQ, bytes_updQ),
-        "seg_update_kernel[P]": (t_updP, bytes_updP),
+    out = {}
+    # --- the kernels of the step, timed inside the running (pipelined, eager) step -------------------
+    nb = len(batches)
+    prof = live_kernel_profile(K, lambda t: eager_step(t % nb), 4 * nb)
+    cQ = [segment_census(torch.cat((bi, bj))) for _, bi, bj in batches]
+    cP = [segment_census(bu) for bu, _, _ in batches]
+    mean = lambda xs: sum(xs) / len(xs)
+    # algorithmic bytes per launch (DESIGN.md "Kernels"): a destination row costs its (w, m, v) read + written and
+    # 8 B of segment metadata; a contribution costs its source row and 12 B (source index, position, coefficient)
+    upd = lambda c, short: (mean([x[0 if short else 2] for x in c]) * (rows_rw * row + 8)
+                            + mean([x[1 if short else 3] for x in c]) * (row + 12))
+    alg = {
+        "bpr_forward_kernel": B * (12 + 3 * row + row + 16),            # ids, 3 rows; stash row, g, loss, 2 coefficients
+        "seg_update_kernel<item side>": upd(cQ, True),
+        "seg_update_kernel<user side>": upd(cP, True),
+        # long segments: pass 1 reads the contributions and writes one partial row per 32; pass 2 reads the partial
+        # rows and reads + writes (w, m, v)
+        "seg_long_partial_kernel": mean([x[3] for x in cQ]) * (row + 12) + mean([x[4] for x in cQ]) * row,
+        "seg_long_combine_kernel": mean([x[4] for x in cQ]) * row + mean([x[2] for x in cQ]) * (rows_rw * row + 8),
     }
-    name, (t_dom, b_dom) = max(kern.items(), key=lambda kv: kv[1][0])
-    ach = b_dom / (t_dom * 1e-3) / 1e9
-    out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                       "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_ms": t_dom,
-                       "algorithmic_bytes_per_launch": b_dom}
-    out["kernels"] = {n: {"avg_ms": t, "algorithmic_GBps": b / (t * 1e-3) / 1e9, "frac_hbm_peak": b / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-                      for n, (t, b) in kern.items()}
-    out["kernels"]["segment_plan[Q,2B]"] = {"avg_ms": t_planQ}
-    out["kernels"]["segment_plan[P,B]"] = {"avg_ms": t_planP}
+    traffic = {}
+    tp_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tp_path):           # HBM-side bytes per launch from rocprofv3 --pmc passes (tools/pmc_traffic.py)
+        with open(tp_path) as f:
+            traffic = json.load(f).get("kernels", {})
+    kern = {}
+    for nm, ts in prof.items():
+        calls, t = len(ts), sum(ts) / len(ts)
+        e = {"avg_ms": t, "min_ms": min(ts), "max_ms": max(ts), "calls_per_step": calls / (4 * nb),
+             "rocprof_name": ROCPROF_NAMES.get(nm, nm)}
+        if nm in alg and t > 0:
+            e["algorithmic_bytes_per_launch"] = int(alg[nm])
+            e["algorithmic_GBps"] = alg[nm] / (t * 1e-3) / 1e9
+            e["frac_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBPS
+        if nm in traffic:
+            e["traffic_bytes_per_launch"] = traffic[nm]
+        kern[nm] = e
+    out["kernels"] = kern
+    # dominant kernel = the one that moves the most bytes per step (the long-segment passes run beside it on a
+    # helper stream and their durations are mostly dispatch waits behind its workgroups)
+    name = max((n for n in kern if n in alg), key=lambda n: alg[n] * kern[n]["calls_per_step"])
+    d = kern[name]
+    out["roofline"] = {"bound": "hbm", "kernel": d["rocprof_name"], "achieved": d["algorithmic_GBps"],
+                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["frac_hbm_peak"],
+                       "traffic": (traffic.get(name) or {}).get("hbm_bytes"), "avg_ms": d["avg_ms"],
+                       "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                       "timing": "start/stop HIP events attached to each launch on its own stream (hipExtLaunchKernelGGL"
+                                 " via dr_profile_enable), inside the pipelined eager step"}
+    # standalone plan cost (generic API; the step itself uses one combined 3B-key plan built one batch ahead)
+    idsQ = torch.cat((i, j)).contiguous()
+    planQ = K.SegmentPlan(idsQ, args.items)
+    out["kernels"]["segment_plan[2B keys, standalone API]"] = {
+        "avg_ms": ev_time(lambda: K.SegmentPlan(idsQ, args.items, planQ.ws), 20, stream)}
     step_bytes = B * (12 + 3 * rows_rw * row)                          # SURVEY 8(d): 9228 B / 3084 B per sample at k=128
     out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_sample": step_bytes // B,
                             "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

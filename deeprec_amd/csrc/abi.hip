@@ -92,3 +92,59 @@ extern "C" int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* strea
     DR_CHECK_LAUNCH("dr_sum_f32");
     return DR_OK;
 }
+
+// ---- optional per-kernel timing -----------------------------------------------------------------------------
+namespace dr {
+bool g_prof_on = false;
+namespace {
+constexpr int PROF_CAP = 4096;
+struct ProfRec {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+ProfRec g_prof[PROF_CAP];
+int g_prof_n = 0;         // records in use since the last collect
+int g_prof_events = 0;    // records whose events exist
+}  // namespace
+
+bool prof_slot(const char* name, hipEvent_t* e0, hipEvent_t* e1) {
+    if (g_prof_n >= PROF_CAP) return false;
+    ProfRec& r = g_prof[g_prof_n];
+    if (g_prof_n >= g_prof_events) {
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return false;
+        g_prof_events = g_prof_n + 1;
+    }
+    r.name = name;
+    *e0 = r.e0;
+    *e1 = r.e1;
+    ++g_prof_n;
+    return true;
+}
+}  // namespace dr
+
+extern "C" int32_t dr_profile_enable(int32_t on) {
+    dr::g_prof_on = on != 0;
+    if (on) dr::g_prof_n = 0;
+    return DR_OK;
+}
+
+extern "C" int32_t dr_profile_collect(char* names, int64_t names_bytes, float* ms, int32_t cap) {
+    DR_REQUIRE(names && names_bytes > 0 && ms && cap >= 0, "dr_profile_collect: bad arguments");
+    int n = 0;
+    int64_t off = 0;
+    names[0] = 0;
+    for (int i = 0; i < dr::g_prof_n && n < cap; ++i) {
+        dr::ProfRec& r = dr::g_prof[i];
+        float t = 0.0f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
+        const int64_t len = (int64_t)strlen(r.name);
+        if (off + len + 2 > names_bytes) break;
+        memcpy(names + off, r.name, len);
+        off += len;
+        names[off++] = '\n';
+        names[off] = 0;
+        ms[n++] = t;
+    }
+    dr::g_prof_n = 0;
+    return n;
+}

@@ -1,6 +1,7 @@
 // Shared host/device helpers for the deeprec_amd HIP kernels (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -41,6 +42,22 @@ char* last_error_buf();  // thread-local, defined in abi.hip
     do {                                                                               \
         hipError_t e_ = (call);                                                        \
         if (e_ != hipSuccess) DR_FAIL(DR_ERR_LAUNCH, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- optional per-kernel timing (dr_profile_enable / dr_profile_collect, defined in abi.hip) ----
+// DR_LAUNCH_NAMED launches like DR_LAUNCH; while profiling is enabled it goes through hipExtLaunchKernelGGL with a
+// start / stop event pair, which the runtime stamps with the dispatch's own begin / end times (what rocprofv3's
+// kernel trace reports).  Disabled (the default) it costs one load and a branch.  Never enable under capture.
+extern bool g_prof_on;
+bool prof_slot(const char* name, hipEvent_t* e0, hipEvent_t* e1);
+#define DR_LAUNCH_NAMED(name, kernel, grid, block, shmem, stream, ...)                              \
+    do {                                                                                            \
+        hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                  \
+        (void)hipGetLastError();                                                                    \
+        if (dr::g_prof_on && dr::prof_slot(name, &pe0_, &pe1_))                                     \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, pe0_, pe1_, 0, __VA_ARGS__);  \
+        else                                                                                        \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                    \
     } while (0)
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

@@ -427,8 +427,8 @@ static int bpr_forward(const float* P, const float* Q, int64_t num_user, int64_t
     bool ok = false;
 #define DR_F(V_, L_)                                                                                                \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                          \
-        DR_LAUNCH((bpr_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)), dim3(256), 0, st, P, Q,    \
-                           num_user, num_item, k, u, i, j, B, g_out, loss_b, stash, coef2);                         \
+        DR_LAUNCH_NAMED("bpr_forward_kernel", (bpr_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)),         \
+                        dim3(256), 0, st, P, Q, num_user, num_item, k, u, i, j, B, g_out, loss_b, stash, coef2);    \
         ok = true;                                                                                                  \
     }
     DR_SHAPE_DISPATCH(DR_F)

@@ -256,50 +256,38 @@ __global__ __launch_bounds__(256) void seg_meta_kernel(const int32_t* __restrict
 }
 
 // sum of contributions [y0, y1) (one DR_SEG_CHUNK block) for vector column c, sequential in y;
-// the row loads of a block are independent of the running sum, so they are issued 8 at a time
+// the row loads of a block are independent of the running sum, so they are issued UNR at a time (the ragged
+// end of a block is predicated, not serialised: a long-segment pass is a chain of dependent memory round trips
+// and nothing else)
 template <int V, int UNR>
 __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int c, float (&acc)[V]) {
 #pragma unroll
     for (int x = 0; x < V; ++x) acc[x] = 0.0f;
     const float* __restrict__ src = a.src;
-    int y = y0;
-    for (; y + UNR <= y1; y += UNR) {
+    for (int y = y0; y < y1; y += UNR) {
+        const int n = y1 - y;  // >= 1; entries q >= n do not exist
         float v[UNR][V];
         float cf[UNR];
         int si[UNR];
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
-            si[q] = a.msrc[y + q];
-            cf[q] = a.coef ? a.coef[a.spos[y + q] - a.pos_lo] : 1.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < UNR; ++q) {
-            if (si[q] >= 0) {
-                vload<V>(v[q], src + (int64_t)si[q] * a.k + c * V);
-            } else {
-                cf[q] = 0.0f;
-#pragma unroll
-                for (int x = 0; x < V; ++x) v[q][x] = 0.0f;
+            si[q] = -1;
+            cf[q] = 1.0f;
+            if (q < n) {
+                si[q] = a.msrc[y + q];
+                if (a.coef) cf[q] = a.coef[a.spos[y + q] - a.pos_lo];
             }
         }
 #pragma unroll
+        for (int q = 0; q < UNR; ++q)
+            if (si[q] >= 0) vload<V>(v[q], src + (int64_t)si[q] * a.k + c * V);
+#pragma unroll
         for (int q = 0; q < UNR; ++q) {
+            if (si[q] >= 0) {
 #pragma unroll
-            for (int x = 0; x < V; ++x) acc[x] = acc[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
+                for (int x = 0; x < V; ++x) acc[x] = acc[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
+            }
         }
-    }
-    for (; y < y1; ++y) {
-        const int si = a.msrc[y];
-        if (si < 0) continue;
-        float v[V];
-        vload<V>(v, src + (int64_t)si * a.k + c * V);
-        if (a.coef) {
-            const float cf = a.coef[a.spos[y] - a.pos_lo];
-#pragma unroll
-            for (int x = 0; x < V; ++x) v[x] = cf * v[x];
-        }
-#pragma unroll
-        for (int x = 0; x < V; ++x) acc[x] = acc[x] + v[x];
     }
 }
 
@@ -351,15 +339,17 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, f
 }
 
 // short segments (<= LONG_SEG contributions, the common case): one sub-wave per segment
-template <int V, int LPR>
+// PART (compile-time copy of a.part) also gives the two launches of a combined two-table plan distinct kernel
+// names in profiler output: <.., 2> is the item-table side of the fused BPR step, <.., 1> the user-table side.
+template <int V, int LPR, int PART>
 __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
     a.opt = resolve(a.opt);
     constexpr int SPB = 256 / LPR;  // segments per block pass
     const int sub = threadIdx.x / LPR;
     const int lane = threadIdx.x % LPR;
     const int cpr = a.k / V;
-    const int s_lo = (a.part == 2) ? a.hdr[3] : 0;
-    const int s_hi = (a.part == 1) ? a.hdr[3] : a.hdr[0];
+    const int s_lo = (PART == 2) ? a.hdr[3] : 0;
+    const int s_hi = (PART == 1) ? a.hdr[3] : a.hdr[0];
     for (int s = s_lo + blockIdx.x * SPB + sub; s < s_hi; s += gridDim.x * SPB) {
         const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
         if ((int64_t)r >= a.rows) continue;  // sentinel segment of out-of-range ids / the other table's rows
@@ -419,7 +409,7 @@ __global__ __launch_bounds__(256) void seg_long_partial_kernel(SegArgs a) {
         const int c1 = (c0 + DR_SEG_CHUNK < e) ? c0 + DR_SEG_CHUNK : e;
         for (int c = lane; c < cpr; c += LPR) {
             float acc[V];
-            block_sum<V, 8>(a, c0, c1, c, acc);
+            block_sum<V, 16>(a, c0, c1, c, acc);
             vstore<V>(a.partials + (int64_t)pr * a.k + c * V, acc);
         }
     }
@@ -467,6 +457,16 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
 }
 
 template <int V, int LPR>
+static void launch_short(const SegArgs& a, int grid, hipStream_t st) {
+    if (a.part == 2)
+        DR_LAUNCH_NAMED("seg_update_kernel<item side>", (seg_update_kernel<V, LPR, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.part == 1)
+        DR_LAUNCH_NAMED("seg_update_kernel<user side>", (seg_update_kernel<V, LPR, 1>), dim3(grid), dim3(256), 0, st, a);
+    else
+        DR_LAUNCH_NAMED("seg_update_kernel", (seg_update_kernel<V, LPR, 0>), dim3(grid), dim3(256), 0, st, a);
+}
+
+template <int V, int LPR>
 static void launch_seg(const SegArgs& a, int64_t n, hipStream_t main) {
     constexpr int SPB = 256 / LPR;
     int grid = grid_for(n, 1, SPB);
@@ -475,15 +475,16 @@ static void launch_seg(const SegArgs& a, int64_t n, hipStream_t main) {
     hipEvent_t fork = nullptr, join = nullptr;
     hipStream_t st = main;
     if (n > LONG_SEG) st = seg_side_stream(main, &fork, &join);
-    if (st == main) DR_LAUNCH((seg_update_kernel<V, LPR>), dim3(grid), dim3(256), 0, main, a);
+    if (st == main) launch_short<V, LPR>(a, grid, main);
     if (n > LONG_SEG) {
         // partial rows <= n / DR_SEG_CHUNK + n / LONG_SEG ; long segments <= n / LONG_SEG
-        DR_LAUNCH((seg_long_partial_kernel<V, LPR>), dim3(grid_for(n / DR_SEG_CHUNK + n / LONG_SEG + 1, 1, SPB)),
-                  dim3(256), 0, st, a);
-        DR_LAUNCH((seg_long_combine_kernel<V, LPR>), dim3(grid_for(n / LONG_SEG + 1, 1, SPB)), dim3(256), 0, st, a);
+        DR_LAUNCH_NAMED("seg_long_partial_kernel", (seg_long_partial_kernel<V, LPR>),
+                        dim3(grid_for(n / DR_SEG_CHUNK + n / LONG_SEG + 1, 1, SPB)), dim3(256), 0, st, a);
+        DR_LAUNCH_NAMED("seg_long_combine_kernel", (seg_long_combine_kernel<V, LPR>),
+                        dim3(grid_for(n / LONG_SEG + 1, 1, SPB)), dim3(256), 0, st, a);
         if (st != main) {  // the (small) long-segment passes were enqueued first so that they are not starved
             (void)hipEventRecord(join, st);
-            DR_LAUNCH((seg_update_kernel<V, LPR>), dim3(grid), dim3(256), 0, main, a);
+            launch_short<V, LPR>(a, grid, main);
             (void)hipStreamWaitEvent(main, join, 0);
         }
     }

@@ -264,6 +264,18 @@ int32_t dr_adam_tick_f32(float* state, float lr, float beta1, float beta2, void*
 /* Fixed-order sum of x[0..n) into out[0] (deterministic loss reduction). */
 int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream);
 
+/* ---- measurement hooks (no counterpart in the reference) ---------------------------------------------
+ * dr_profile_enable(1): from now on every instrumented kernel launch of this library (the fused step's forward
+ * kernel, the short / long segment update kernels) carries a start / stop HIP event pair that the runtime stamps
+ * with the dispatch's own begin and end (hipExtLaunchKernelGGL), on the stream it is launched on;
+ * dr_profile_enable(0) stops it.  Do not enable while a stream is being captured into a graph.  Not
+ * thread-safe: one profiling host thread at a time.
+ * dr_profile_collect: waits for the recorded launches, writes up to `cap` durations (milliseconds, launch
+ * order) to ms[] and their kernel names, newline-separated, to names[]; returns the number of records and
+ * clears the list.  bench.py's `roofline` comes from these numbers. */
+int32_t dr_profile_enable(int32_t on);
+int32_t dr_profile_collect(char* names, int64_t names_bytes, float* ms, int32_t cap);
+
 #ifdef __cplusplus
 }
 #endif
