@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel / eval / gather extras")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying hipGraphs")
+    ap.add_argument("--sharded", action="store_true",
+                    help="run the row-sharded (multi-GPU) step even at --gpus 1, to price its exchange logic without a fabric")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="build each batch's segment plans inside its own step (dr_bpr_step_f32) instead of one batch ahead")
     return ap.parse_args()
@@ -120,7 +122,7 @@ def main():
     launch = "eager"
 
     batches = make_batches(args, rank, device)
-    if world == 1:
+    if world == 1 and not args.sharded:
         P = torch.empty((args.users, k), dtype=torch.float32, device=device)
         Q = torch.empty((args.items, k), dtype=torch.float32, device=device)
         K.init_normal_(P, 1, 0.01)
@@ -220,11 +222,11 @@ def main():
                                                               "Adam" if adam else "SGD"),
                    "users": args.users, "items": args.items, "k": k, "batch_per_gpu": B,
                    "optimizer": args.opt, "reg_mode": "touched", "launch": launch,
-                   "parallelism": "single" if world == 1 else "row-sharded x%d (all-to-all)" % world},
+                   "parallelism": "single" if world == 1 and not args.sharded else "row-sharded x%d (all-to-all)" % world},
         "last_loss_sum": last_loss,
     }
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not args.sharded:
         result.update(extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step, eager_step))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args)

@@ -845,3 +845,86 @@ extern "C" int32_t dr_rownorm_clip_f32(float* table, int64_t rows, int32_t k, fl
     DR_CHECK_LAUNCH("dr_rownorm_clip_f32");
     return DR_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// stable bucketing of small keys (routing a batch to the ranks that own its rows)
+// ---------------------------------------------------------------------------------------
+namespace dr {
+struct BucketLayout {
+    int64_t keys_in, keys_out, vals_in, temp, temp_bytes, total;
+};
+static int bucket_layout(int64_t n, BucketLayout* L) {
+    size_t t_sort = 0;
+    const int64_t nn = n > 0 ? n : 1;
+    hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, int32_t*, int32_t*>(
+        nullptr, t_sort, nullptr, nullptr, nullptr, nullptr, (size_t)nn, 0, 32, 0, false);
+    if (e != hipSuccess) return -1;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    L->keys_in = take(nn * 4);
+    L->keys_out = take(nn * 4);
+    L->vals_in = take(nn * 4);
+    L->temp_bytes = (int64_t)t_sort + 256;
+    L->temp = take(L->temp_bytes);
+    L->total = off;
+    return 0;
+}
+
+// keys out of range go to the extra bucket nkeys (never produced by the sharding code; kept out of the counts)
+__global__ __launch_bounds__(256) void bucket_keys_kernel(const int32_t* __restrict__ keys, int64_t n, int nkeys,
+                                                          uint32_t* __restrict__ kout, int32_t* __restrict__ vout,
+                                                          long long* __restrict__ counts) {
+    __shared__ int hist[257];
+    for (int b = threadIdx.x; b <= nkeys; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int kx = keys[e];
+        const int b = (kx >= 0 && kx < nkeys) ? kx : nkeys;
+        kout[e] = (uint32_t)b;
+        vout[e] = (int32_t)e;
+        atomicAdd(&hist[b], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nkeys; b += 256)
+        if (hist[b]) atomicAdd((unsigned long long*)&counts[b], (unsigned long long)hist[b]);
+}
+}  // namespace dr
+
+extern "C" int64_t dr_bucket_order_bytes(int64_t n) {
+    if (n < 0) return DR_ERR_ARG;
+    BucketLayout L;
+    if (bucket_layout(n, &L) != 0) return DR_ERR_LAUNCH;
+    return L.total;
+}
+
+extern "C" int32_t dr_bucket_order_i32(const int32_t* keys, int64_t n, int32_t nkeys, int32_t* order, int64_t* counts,
+                                       void* ws, int64_t ws_bytes, void* stream) {
+    DR_REQUIRE(n >= 0 && n < (1ll << 31) - 1 && nkeys >= 1 && nkeys <= 256, "dr_bucket_order_i32: bad sizes (nkeys in [1,256])");
+    DR_REQUIRE(counts != nullptr, "dr_bucket_order_i32: counts is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    DR_HIP(hipMemsetAsync(counts, 0, (size_t)nkeys * 8, st));
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(keys && order && ws && ((uintptr_t)ws % 256 == 0), "dr_bucket_order_i32: NULL / misaligned pointer");
+    BucketLayout L;
+    if (bucket_layout(n, &L) != 0) DR_FAIL(DR_ERR_LAUNCH, "dr_bucket_order_i32: rocprim size query failed");
+    if (ws_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_bucket_order_i32: workspace %lld < required %lld", (long long)ws_bytes,
+                (long long)L.total);
+    char* base = (char*)ws;
+    uint32_t* kin = (uint32_t*)(base + L.keys_in);
+    uint32_t* kout = (uint32_t*)(base + L.keys_out);
+    int32_t* vin = (int32_t*)(base + L.vals_in);
+    DR_LAUNCH(bucket_keys_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n, (int)nkeys, kin, vin,
+              (long long*)counts);
+    DR_CHECK_LAUNCH("bucket_keys_kernel");
+    unsigned end_bit = 1;
+    while ((1u << end_bit) <= (unsigned)nkeys) ++end_bit;  // keys 0 .. nkeys
+    size_t tb = (size_t)L.temp_bytes;
+    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, kin, kout, vin, order, (size_t)n, 0,
+                                                               end_bit, st, false)));
+    return DR_OK;
+}

@@ -142,6 +142,21 @@ class SegmentPlan:
         return sl(ptrs[0], self.n).clone(), sl(ptrs[1], nseg).clone(), sl(ptrs[2], nseg + 1).clone()
 
 
+def bucket_order(keys, nkeys):
+    """Stable bucketing of small integer keys in [0, nkeys) (routing by owner rank, deeprec_amd/sharding.py):
+    returns (order int32 [n]: positions in ascending key order, ties in input order; counts int64 [nkeys]).
+    No host synchronisation."""
+    keys = _i32(keys, "keys")
+    n = keys.numel()
+    order = torch.empty(n, dtype=torch.int32, device=keys.device)
+    counts = torch.empty(nkeys, dtype=torch.int64, device=keys.device)
+    need = check(_abi.lib().dr_bucket_order_bytes(n), "dr_bucket_order_bytes")
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=keys.device)
+    check(_abi.lib().dr_bucket_order_i32(_ptr(keys), n, int(nkeys), _ptr(order), _ptr(counts), _ptr(ws), ws.numel(),
+                                         _stream()), "dr_bucket_order_i32")
+    return order, counts
+
+
 def scatter_add(gtable, ids, src, src_idx=None, coef=None, plan=None):
     """gtable[ids[e]] += coef[e] * src[src_idx[e]] in place, duplicates summed deterministically."""
     gtable = _req(gtable, torch.float32, "gtable")

@@ -9,6 +9,8 @@ better than contiguous blocks).  A training step exchanges, per table,
     rows  <- owners        all-to-all-v   (4k B per lookup, owners run the gather kernel)
     grads -> owners        all-to-all-v   (4k B per lookup)
 
+(the u list in one exchange, the i and j lists together in a second one: StepRoutes)
+
 and the owners run the deterministic sorted-segment row update on what they received.  The received
 contributions are laid out in ascending *global batch position* (rank-major, then batch order; for Q
 all positive-item contributions precede all negative-item ones), i.e. exactly the order a single
@@ -108,32 +110,129 @@ class ShardedTable:
             self.w[l0:l0 + part.shape[0]].copy_(part)
 
 
+_HELPER = {}
+
+
+def _helper_stream(device):
+    key = (device.type, device.index)
+    if key not in _HELPER:
+        _HELPER[key] = torch.cuda.Stream(device=device)
+    return _HELPER[key]
+
+
+class StepRoutes:
+    """Routing of one BPR batch: u -> owners of P rows, (i, j) -> owners of Q rows.
+
+    One count exchange and ONE host synchronisation serve both tables.  Wire order towards owner r is, per
+    table, the requester's batch order (stable bucket by owner); for Q each requester sends [its i's | its j's].
+    The owner-side canonical contribution order -- all positive items of the global batch (rank-major, batch
+    order), then all negative items -- is the index list `q_perm` into what was received, so no payload is
+    ever re-ordered in memory: kernels take it as `src_idx`."""
+
+    def __init__(self, ops, u, i, j, world, rank, group=None):
+        self.world, self.rank, self.group = world, rank, group
+        dev = u.device
+        B = u.numel()
+        self.B = B
+        W = world
+        ij = torch.cat((i, j))
+        oq = (ij % W) * 2
+        oq[B:] += 1                                              # key = owner * 2 + part (0: i, 1: j)
+        self.order_u, cu = ops.bucket_order((u % W).to(torch.int32), W)
+        self.order_q, cq = ops.bucket_order(oq.to(torch.int32), 2 * W)
+        self.order_u, self.order_q = self.order_u.long(), self.order_q.long()
+        counts = torch.cat((cu[:, None], cq.view(W, 2)), 1)
+        recv = torch.empty_like(counts)
+        if W > 1:
+            dist.all_to_all_single(recv, counts, group=group)    # row s of recv = what rank s sends here
+        else:
+            recv.copy_(counts)
+        both = torch.stack((counts, recv)).tolist()              # the step's one host sync (variable split sizes)
+        sc, rc = both
+        self.send_u = [c[0] for c in sc]
+        self.recv_u = [c[0] for c in rc]
+        self.send_q = [c[1] + c[2] for c in sc]
+        self.recv_q = [c[1] + c[2] for c in rc]
+        self.n_recv_u, self.n_recv_q = sum(self.recv_u), sum(self.recv_q)
+        # local row ids at the owners
+        self.rows_u = self._a2a(torch.div(u, W, rounding_mode="floor").to(torch.int32)[self.order_u].contiguous(),
+                                self.n_recv_u, self.recv_u, self.send_u)
+        self.rows_q = self._a2a(torch.div(ij, W, rounding_mode="floor").to(torch.int32)[self.order_q].contiguous(),
+                                self.n_recv_q, self.recv_q, self.send_q)
+        # canonical owner-side order of the Q contributions: every source's i-part, then every source's j-part
+        off, ip, jp = 0, [], []
+        for s in range(W):
+            ci, cj = rc[s][1], rc[s][2]
+            ip.append((off, off + ci))
+            jp.append((off + ci, off + ci + cj))
+            off += ci + cj
+        self.q_perm = torch.cat([torch.arange(lo, hi, dtype=torch.int32, device=dev) for lo, hi in ip + jp]) \
+            if off else torch.zeros(0, dtype=torch.int32, device=dev)
+        # where each sample's rows sit in the fetched (owner-sorted) buffers
+        ar = torch.arange(B, dtype=torch.int32, device=dev)
+        self.inv_u = torch.empty(B, dtype=torch.int32, device=dev)
+        self.inv_u[self.order_u] = ar
+        self.inv_q = torch.empty(2 * B, dtype=torch.int32, device=dev)
+        self.inv_q[self.order_q] = torch.arange(2 * B, dtype=torch.int32, device=dev)
+
+    def _a2a(self, send, n_out, out_splits, in_splits):
+        out = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if self.world > 1:
+            dist.all_to_all_single(out, send, out_splits, in_splits, group=self.group)
+        else:
+            out.copy_(send)
+        return out
+
+    def fetch_u(self, rows_at_owner):   # [n_recv_u, k] -> [B, k], requester's owner-sorted order
+        return self._a2a(rows_at_owner, self.B, self.send_u, self.recv_u)
+
+    def fetch_q(self, rows_at_owner):   # [n_recv_q, k] -> [2B, k]
+        return self._a2a(rows_at_owner, 2 * self.B, self.send_q, self.recv_q)
+
+    def push_u(self, rows_sorted):      # [B, k] in owner-sorted order -> [n_recv_u, k], rank-major
+        return self._a2a(rows_sorted, self.n_recv_u, self.recv_u, self.send_u)
+
+    def push_q(self, rows_sorted):      # [2B, k] -> [n_recv_q, k], wire order (see q_perm)
+        return self._a2a(rows_sorted, self.n_recv_q, self.recv_q, self.send_q)
+
+
 def sharded_bpr_step(ops, P, Q, u, i, j, opt, group=None):
     """One BPR-MF step (bprmf.py:114-123) over row-sharded P, Q for this rank's batch (u, i, j) of
-    GLOBAL ids (int32 [B]).  Returns this rank's loss sum (device scalar tensor)."""
+    GLOBAL ids (int32 [B]).  Returns this rank's loss sum (device scalar tensor).
+
+    7 collectives (1 count, 2 id, 2 row, 2 gradient all-to-alls) and one host synchronisation per step; no
+    payload row is copied except by the kernels that produce or consume it (lookups and gradient rows are
+    addressed through index lists)."""
     world, rank = P.world, P.rank
-    dev = u.device
     B = u.numel()
-    ex_u = Exchange(u, world, rank, group)
-    ex_i = Exchange(i, world, rank, group)
-    ex_j = Exchange(j, world, rank, group)
-    # rows <- owners (the owners run K1 on their shard)
-    pu = ex_u.fetch(ops.gather(P.w, ex_u.owner_rows))
-    qi = ex_i.fetch(ops.gather(Q.w, ex_i.owner_rows))
-    qj = ex_j.fetch(ops.gather(Q.w, ex_j.owner_rows))
-    # local interaction + loss on compact tables: row b of pu / [qi ; qj]
-    ar = torch.arange(B, dtype=torch.int32, device=dev)
-    qc = torch.cat((qi, qj))
-    g, loss_b, stash = ops.bpr_forward(pu, qc, ar, ar, ar + B)
-    # grads -> owners, then the owners' deterministic segment update.  Q first is not needed here
-    # (pu is a private pre-step copy), but the contribution ORDER is: [all i ; all j], rank-major.
-    gi = ops.scale_rows(pu, g)
-    gj = ops.scale_rows(pu, -g)
-    q_src = torch.cat((ex_i.push(gi), ex_j.push(gj)))
-    q_ids = torch.cat((ex_i.owner_rows, ex_j.owner_rows))
-    p_src = ex_u.push(stash)
-    ops.sparse_row_update(Q.w, Q.slot(0), Q.slot(1), q_ids, q_src, opt)
-    ops.sparse_row_update(P.w, P.slot(0), P.slot(1), ex_u.owner_rows, p_src, opt)
+    rt = StepRoutes(ops, u, i, j, world, rank, group)
+    q_ids = rt.rows_q[rt.q_perm.long()].contiguous()
+    # The owners' segment plans depend on the routed ids only: build them on a helper stream while the rows and
+    # gradients travel.  (Namespaces without SegmentPlan -- the CPU oracle in tests -- plan inside the update.)
+    plan_q = plan_p = side = None
+    if world > 1 and hasattr(ops, "SegmentPlan") and u.is_cuda:   # one rank: nothing travels, nothing to hide behind
+        main = torch.cuda.current_stream()
+        side = _helper_stream(u.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            plan_q = ops.SegmentPlan(q_ids, Q.w.shape[0], k_max=Q.k)
+            plan_p = ops.SegmentPlan(rt.rows_u, P.w.shape[0], k_max=P.k)
+    # rows <- owners (the owners run K1 on their shard); they arrive in owner-sorted order and stay there
+    pu = rt.fetch_u(ops.gather(P.w, rt.rows_u))
+    qc = rt.fetch_q(ops.gather(Q.w, rt.rows_q))
+    # local interaction + loss: sample b reads pu[inv_u[b]], qc[inv_q[b]], qc[inv_q[B + b]]
+    g, loss_b, stash = ops.bpr_forward(pu, qc, rt.inv_u, rt.inv_q[:B].contiguous(), rt.inv_q[B:].contiguous())
+    # grads -> owners, produced directly in wire order.  Q: +g * p_u for the i-entry, -g * p_u for the j-entry
+    # of each sample (pu is a private pre-step copy, so the Q-before-P ordering of the fused step is moot here)
+    coef = torch.cat((g, -g))[rt.order_q].contiguous()
+    src_row = rt.inv_u[(rt.order_q % B)].contiguous()
+    q_grad = rt.push_q(ops.scale_rows(pu, coef, src_row))
+    p_grad = rt.push_u(ops.gather(stash, rt.order_u.to(torch.int32)))
+    # the owners' deterministic segment updates; contributions in ascending global batch position
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+    ops.sparse_row_update(Q.w, Q.slot(0), Q.slot(1), q_ids, q_grad, opt, src_idx=rt.q_perm, plan=plan_q)
+    ops.sparse_row_update(P.w, P.slot(0), P.slot(1), rt.rows_u, p_grad, opt, plan=plan_p)
     return ops.sum_f32(loss_b)
 
 

@@ -264,6 +264,14 @@ int32_t dr_adam_tick_f32(float* state, float lr, float beta1, float beta2, void*
 /* Fixed-order sum of x[0..n) into out[0] (deterministic loss reduction). */
 int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream);
 
+/* ---- multi-GPU routing helper (no counterpart in the reference, which is single-device) ----
+ * Stable bucketing of n small keys in [0, nkeys), nkeys <= 256 (key = owning rank of a looked-up row):
+ * order[x] = position of the x-th element in ascending key order, ties in input order; counts[b] = number of
+ * keys equal to b.  Keys outside the range sort last and are not counted.  ws: dr_bucket_order_bytes(n). */
+int64_t dr_bucket_order_bytes(int64_t n);
+int32_t dr_bucket_order_i32(const int32_t* keys, int64_t n, int32_t nkeys, int32_t* order, int64_t* counts, void* ws,
+                            int64_t ws_bytes, void* stream);
+
 /* ---- measurement hooks (no counterpart in the reference) ---------------------------------------------
  * dr_profile_enable(1): from now on every instrumented kernel launch of this library (the fused step's forward
  * kernel, the short / long segment update kernels) carries a start / stop HIP event pair that the runtime stamps

@@ -18,6 +18,12 @@ def gather(table, ids, oob="zero"):
     return torch.from_numpy(ro.gather(_n(table), _n(ids), oob))
 
 
+def bucket_order(keys, nkeys):
+    kk = _n(keys).astype(np.int64)
+    order = np.argsort(kk, kind="stable").astype(np.int32)
+    return torch.from_numpy(order), torch.from_numpy(np.bincount(kk, minlength=nkeys).astype(np.int64))
+
+
 def bpr_forward(P, Q, u, i, j):
     lb, g, _ = ro.bpr_forward(_n(P), _n(Q), _n(u), _n(i), _n(j))
     stash = (g[:, None] * (ro.gather(_n(Q), _n(i)) - ro.gather(_n(Q), _n(j)))).astype(np.float32)

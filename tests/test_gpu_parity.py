@@ -537,3 +537,45 @@ def test_score_topk_large_property(dev):
             r = rank[2 * u + x]
             if r >= 0:
                 assert (r < K_) == (t in idx[u])
+
+
+# ------------------------------------------------------------------ sharded step, real kernels, world 1
+def test_sharded_step_world1_equals_fused_step(dev):
+    """deeprec_amd/sharding.py on the HIP kernels (one rank, so no fabric): the routed lookups, index-addressed
+    forward, wire-order gradient rows and owner-side updates give the fused step's tables bit for bit."""
+    from deeprec_amd import kernels as K
+    from deeprec_amd import sharding as sh
+    rng = np.random.default_rng(21)
+    nu, ni, k, B = 5000, 700, 64, 4096
+    P0 = (rng.standard_normal((nu, k)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((ni, k)) * 0.1).astype(np.float32)
+    Pt = sh.ShardedTable(nu, k, 1, 0, dev, 2)
+    Qt = sh.ShardedTable(ni, k, 1, 0, dev, 2)
+    Pt.load_global(T(P0, dev))
+    Qt.load_global(T(Q0, dev))
+    P, Q = T(P0, dev), T(Q0, dev)
+    sP = [torch.zeros_like(P), torch.zeros_like(P)]
+    sQ = [torch.zeros_like(Q), torch.zeros_like(Q)]
+    ws = K.StepWorkspace(B, k, nu, ni, K.REG_TOUCHED, dev)
+    for t in range(1, 4):
+        u = T(rng.integers(0, nu, B).astype(np.int32), dev)
+        i = T((rng.zipf(1.2, B) % ni).astype(np.int32), dev)
+        j = T(rng.integers(0, ni, B).astype(np.int32), dev)
+        opt = K.opt_params(K.OPT_ADAM, lr=0.05, alpha=float(ro.adam_alpha(1e-3, 0.9, 0.999, t)), eps=1e-7, reg=0.01,
+                           reg_mode=K.REG_TOUCHED)
+        l1 = sh.sharded_bpr_step(K, Pt, Qt, u, i, j, opt)
+        l2 = K.bpr_step(P, Q, sP, sQ, u, i, j, opt, ws)
+        assert np.array_equal(N(Pt.w).view(np.uint32), N(P).view(np.uint32)), "step %d: P differs" % t
+        assert np.array_equal(N(Qt.w).view(np.uint32), N(Q).view(np.uint32)), "step %d: Q differs" % t
+        assert np.array_equal(N(Qt.slots[1]).view(np.uint32), N(sQ[1]).view(np.uint32))
+        np.testing.assert_allclose(float(l1), float(l2), rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,nkeys", [(0, 4), (1, 1), (1000, 3), (131072, 16), (70000, 256)])
+def test_bucket_order_is_stable_counting_sort(dev, n, nkeys):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(n + nkeys)
+    keys = rng.integers(0, nkeys, n).astype(np.int32)
+    order, counts = K.bucket_order(T(keys, dev), nkeys)
+    assert np.array_equal(N(order), np.argsort(keys, kind="stable").astype(np.int32))
+    assert np.array_equal(N(counts), np.bincount(keys, minlength=nkeys))
