@@ -358,6 +358,17 @@ def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step,
     out["gather"]["users_uniform_10M_4Mrows"] = {"rows": 1 << 22, "avg_ms": t_big, "GBps": gb(1 << 22, t_big),
                                                  "frac_hbm_peak": gb(1 << 22, t_big) / HBM_PEAK_GBPS}
     del big
+    # --- negative sampler: one draw per positive from all items minus 100 seen items / user
+    ncsr = min(args.users, 1_000_000)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(11)
+    seen = torch.sort(torch.randint(0, args.items, (ncsr, 100), device=device, generator=gen), 1)[0].to(torch.int32)
+    sptr = (torch.arange(ncsr + 1, device=device) * 100).to(torch.int32)
+    su = torch.randint(0, ncsr, (B,), device=device, generator=gen).to(torch.int32)
+    t_ns = ev_time(lambda: K.sample_negatives(sptr, seen.reshape(-1), su, args.items, 5), 20, stream)
+    out["neg_sampler"] = {"draws": B, "seen_per_user": 100, "users_in_csr": ncsr, "avg_ms": t_ns,
+                          "draws_per_s": B / (t_ns * 1e-3)}
+    del seen, sptr, su
     # --- K6: top-10 eval over the full catalog, 100 masked train items / user, 1 held-out -----
     Nu = args.eval_users
     gen = torch.Generator(device=device)

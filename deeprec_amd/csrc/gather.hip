@@ -170,3 +170,73 @@ extern "C" int32_t dr_gather_f32(const float* table, int64_t rows, int32_t k, co
     DR_CHECK_LAUNCH("dr_gather_f32");
     return DR_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// on-device negative sampler (bprmf.py:126-133,175-181)
+// ---------------------------------------------------------------------------------------
+namespace dr {
+// 32 uniform bits of the counter-based generator shared with dr_init_normal_f32 (splitmix64 finaliser)
+__host__ __device__ inline uint32_t counter_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+// out[e*n_neg + d] = neg_items[u][s], s = floor(r * |neg_items[u]| / 2^32): the s-th item (ascending) that is
+// NOT in the user's sorted train list -- found by a binary search for the largest prefix of the train list
+// that lies before the answer (train[p] - p <= s), no rejection loop and no U x I structure.
+__global__ __launch_bounds__(256) void sample_neg_kernel(const int32_t* __restrict__ train_ptr,
+                                                         const int32_t* __restrict__ train_idx,
+                                                         const int32_t* __restrict__ users, int64_t n, int n_neg,
+                                                         int64_t num_user, int64_t num_item, int64_t first_item,
+                                                         uint64_t seed, uint64_t offset, int32_t* __restrict__ out) {
+    const int64_t total = n * n_neg;
+    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < total; x += (int64_t)gridDim.x * 256) {
+        const int64_t e = x / n_neg;
+        const int64_t u = users[e];
+        int32_t res = -1;
+        if (u >= 0 && u < num_user) {
+            int lo0 = train_ptr[u];
+            const int hi0 = train_ptr[u + 1];
+            // train items below first_item are outside the candidate range (1-based item ids of the seq loaders)
+            {
+                int a = lo0, b = hi0;
+                while (a < b) {
+                    const int m = (a + b) >> 1;
+                    if (train_idx[m] < first_item) a = m + 1; else b = m;
+                }
+                lo0 = a;
+            }
+            const int64_t cnt = (num_item - first_item) - (hi0 - lo0);
+            if (cnt > 0) {
+                const uint64_t r = counter_u32(seed, offset + (uint64_t)x);
+                const int64_t sidx = (int64_t)((r * (uint64_t)cnt) >> 32);
+                int lo = 0, hi = hi0 - lo0;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int64_t)train_idx[lo0 + mid] - first_item - mid <= sidx) lo = mid + 1; else hi = mid;
+                }
+                res = (int32_t)(sidx + lo + first_item);
+            }
+        }
+        out[x] = res;
+    }
+}
+}  // namespace dr
+
+extern "C" int32_t dr_sample_negatives_i32(const int32_t* train_ptr, const int32_t* train_idx, const int32_t* users,
+                                           int64_t n, int32_t n_neg, int64_t num_user, int64_t num_item,
+                                           int64_t first_item, uint64_t seed, uint64_t offset, int32_t* out,
+                                           void* stream) {
+    DR_REQUIRE(n >= 0 && n_neg >= 1 && num_user >= 0 && num_item >= 0 && first_item >= 0 && first_item <= num_item,
+               "dr_sample_negatives_i32: bad sizes");
+    DR_REQUIRE(num_item < (1ll << 31), "dr_sample_negatives_i32: num_item too large for int32 item ids");
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(train_ptr && users && out && (train_idx || num_user == 0), "dr_sample_negatives_i32: NULL pointer");
+    DR_LAUNCH(dr::sample_neg_kernel, dim3(dr::grid_for(n * n_neg, 256)), dim3(256), 0, (hipStream_t)stream, train_ptr,
+              train_idx, users, n, (int)n_neg, num_user, num_item, first_item, seed, offset, out);
+    DR_CHECK_LAUNCH("dr_sample_negatives_i32");
+    return DR_OK;
+}

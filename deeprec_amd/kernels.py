@@ -142,6 +142,21 @@ class SegmentPlan:
         return sl(ptrs[0], self.n).clone(), sl(ptrs[1], nseg).clone(), sl(ptrs[2], nseg + 1).clone()
 
 
+def sample_negatives(train_ptr, train_idx, users, num_item, seed, offset=0, n_neg=1, first_item=0):
+    """n_neg uniform draws per entry of `users` from the items the user has not interacted with
+    (bprmf.py:126-133,175-181), from the train CSR (int32 ptr[U+1], idx ascending per user).  int32 [n, n_neg];
+    -1 where a user has no candidate."""
+    train_ptr = _i32(train_ptr, "train_ptr")
+    train_idx = _i32(train_idx, "train_idx")
+    users = _i32(users, "users")
+    n = users.numel()
+    out = torch.empty((n, n_neg), dtype=torch.int32, device=users.device)
+    check(_abi.lib().dr_sample_negatives_i32(_ptr(train_ptr), _ptr(train_idx), _ptr(users), n, int(n_neg),
+                                             train_ptr.numel() - 1, int(num_item), int(first_item), int(seed),
+                                             int(offset), _ptr(out), _stream()), "dr_sample_negatives_i32")
+    return out
+
+
 def bucket_order(keys, nkeys):
     """Stable bucketing of small integer keys in [0, nkeys) (routing by owner rank, deeprec_amd/sharding.py):
     returns (order int32 [n]: positions in ascending key order, ties in input order; counts int64 [nkeys]).

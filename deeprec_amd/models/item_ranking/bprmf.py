@@ -9,6 +9,9 @@ Deviations from the reference, on purpose:
       (bprmf.py:117), which indexes P with item ids.
   reg_mode: "dense" (default; reference semantics: the l2_loss terms make every row's gradient non-zero,
       bprmf.py:118-120) or "touched" (L2 and Adam moments only on gathered rows; scalable).
+  sampler: "reference" (default: the reference's per-positive np.random stream, bprmf.py:130-133) or "device"
+      (dr_sample_negatives_i32 on the train CSR: same distribution, counter-based stream seeded from np.random,
+      no per-positive Python loop -- SURVEY 8f rank 1).
 """
 import time
 
@@ -22,7 +25,7 @@ from .._common import NegItems, TFOptimizer, device_of, normal_, sample_uniform_
 
 class BPRMF(object):
     def __init__(self, num_user, num_item, learning_rate=0.001, reg_rate=0.1, epoch=500, batch_size=1024,
-                 verbose=False, t=5, display_step=1000, device=None, reg_mode="dense"):
+                 verbose=False, t=5, display_step=1000, device=None, reg_mode="dense", sampler="reference"):
         self.num_user = num_user
         self.num_item = num_item
         self.learning_rate = learning_rate
@@ -34,6 +37,10 @@ class BPRMF(object):
         self.display_step = display_step
         self.device = device_of(device)
         self.reg_mode = {"dense": K.REG_DENSE, "touched": K.REG_TOUCHED}[reg_mode]
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device'")
+        self.sampler = sampler
+        self._train_csr_dev = None
         self.P = None
         self.Q = None
         # tf.keras.optimizers.Adam(learning_rate) (bprmf.py:62): epsilon 1e-7
@@ -84,10 +91,17 @@ class BPRMF(object):
         idxs = np.random.permutation(self.num_training)  # shuffled ordering
         user_random = self.user[idxs]
         item_random = self.item[idxs]
-        item_random_neg = sample_uniform_negatives(user_random, self.neg_items)[:, 0]
         u_d = to_dev(user_random, torch.int32, self.device)
         i_d = to_dev(item_random, torch.int32, self.device)
-        j_d = to_dev(item_random_neg, torch.int32, self.device)
+        if self.sampler == "device":
+            if self._train_csr_dev is None:
+                c = self.neg_items.csr
+                self._train_csr_dev = (to_dev(c.indptr, torch.int32, self.device), to_dev(c.indices, torch.int32, self.device))
+            seed = int(np.random.randint(0, 2 ** 31 - 1))       # one draw per epoch keeps np.random.seed() reproducible
+            j_d = K.sample_negatives(*self._train_csr_dev, u_d, self.num_item, seed)[:, 0].contiguous()
+        else:
+            item_random_neg = sample_uniform_negatives(user_random, self.neg_items)[:, 0]
+            j_d = to_dev(item_random_neg, torch.int32, self.device)
         for i in range(self.total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)
@@ -121,6 +135,18 @@ class BPRMF(object):
                 if s is not None:
                     sl["%s.slot%d" % (n, j)] = s
         save_file({k: v.cpu() for k, v in sl.items()}, path)
+
+    def load(self, path):
+        """Inverse of save(): tables and optimizer slots from a safetensors file (nothing is unpickled)."""
+        from safetensors.torch import load_file
+        sl = load_file(path)
+        self.P = sl["P"].to(self.device)
+        self.Q = sl["Q"].to(self.device)
+        self.num_factor = self.P.shape[1]
+        for n, t in (("P", self.P), ("Q", self.Q)):
+            for j, s in enumerate(self.optimizer.slots_for(t)):
+                if s is not None and "%s.slot%d" % (n, j) in sl:
+                    s.copy_(sl["%s.slot%d" % (n, j)])
 
     def predict(self, user_id, item_id):
         """bprmf.py:168-173 -> np.float32 [N]."""

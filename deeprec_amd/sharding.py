@@ -253,3 +253,61 @@ def all_gather_table(T, group=None):
     dist.all_gather(parts, pad, group=group)
     full = torch.stack(parts, 1).reshape(per * T.world, T.k)   # row r = parts[r % W][r // W]
     return full[:T.rows].contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# sharded checkpoints (the reference's save() is dead code, gmf.py:156-158, bprmf.py:164-166)
+# ----------------------------------------------------------------------------------------------
+def _shard_path(prefix, rank, world):
+    return "%s.rank%05d-of-%05d.safetensors" % (prefix, rank, world)
+
+
+def save_sharded(prefix, tables):
+    """Write this rank's shard of every table in `tables` (name -> ShardedTable) with its optimizer slots to
+    `<prefix>.rank<r>-of-<W>.safetensors`.  Every rank calls it; no communication."""
+    from safetensors.torch import save_file
+    any_t = next(iter(tables.values()))
+    out, meta = {}, {"world": str(any_t.world), "rank": str(any_t.rank)}
+    for name, T in tables.items():
+        out[name + ".w"] = T.w.detach().cpu().contiguous()
+        for j, sl in enumerate(T.slots):
+            out["%s.slot%d" % (name, j)] = sl.detach().cpu().contiguous()
+        meta[name + ".rows"] = str(T.rows)
+        meta[name + ".k"] = str(T.k)
+        meta[name + ".slots"] = str(len(T.slots))
+    path = _shard_path(prefix, any_t.rank, any_t.world)
+    save_file(out, path, metadata=meta)
+    return path
+
+
+def load_sharded(prefix, names, world, rank, device, saved_world=None):
+    """Rebuild this rank's ShardedTables from a checkpoint written at ANY world size (`saved_world`; probed
+    from the file names when None): global row r lived on saved rank r % Ws at local row r // Ws and now lives on
+    rank r % world at local row r // world.  Only safetensors is read (no code is executed from the files)."""
+    import glob
+    import re
+    from safetensors import safe_open
+    if saved_world is None:
+        found = sorted(glob.glob("%s.rank*-of-*.safetensors" % glob.escape(prefix)))
+        if not found:
+            raise FileNotFoundError("no checkpoint shards match %s.rank*-of-*.safetensors" % prefix)
+        saved_world = int(re.search(r"-of-(\d+)\.safetensors$", found[0]).group(1))
+    tables = {}
+    for o in range(saved_world):
+        with safe_open(_shard_path(prefix, o, saved_world), framework="pt", device="cpu") as f:
+            meta = f.metadata()
+            for name in names:
+                rows, k, n_slots = int(meta[name + ".rows"]), int(meta[name + ".k"]), int(meta[name + ".slots"])
+                if name not in tables:
+                    tables[name] = ShardedTable(rows, k, world, rank, device, n_slots)
+                T = tables[name]
+                local_o = (rows - o + saved_world - 1) // saved_world
+                g = o + saved_world * torch.arange(local_o)             # global rows held by saved rank o
+                mine = (g % world) == rank
+                if not bool(mine.any()):
+                    continue
+                dst = torch.div(g[mine], world, rounding_mode="floor").to(T.w.device)
+                T.w[dst] = f.get_tensor(name + ".w")[mine].to(T.w.device)
+                for j in range(n_slots):
+                    T.slots[j][dst] = f.get_tensor("%s.slot%d" % (name, j))[mine].to(T.w.device)
+    return tables

@@ -264,6 +264,19 @@ int32_t dr_adam_tick_f32(float* state, float lr, float beta1, float beta2, void*
 /* Fixed-order sum of x[0..n) into out[0] (deterministic loss reduction). */
 int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream);
 
+/* ---- negative sampler ------------------------------------------------------------
+ * The reference draws, per positive, one (BPRMF bprmf.py:130-133, CML cml.py:108-111) or n_neg (GMF / NeuMF
+ * gmf.py:108-112, AttRec AttRec.py:448-466) items uniformly from neg_items[u] = all items minus the user's
+ * train items, a U x I Python structure (bprmf.py:175-181).  Here: train CSR (idx ascending per user) and
+ * out[e*n_neg + d] = neg_items[users[e]][s] with s = floor(r * |neg_items[u]| / 2^32), r = the 32 high bits of
+ * the counter-based generator of dr_init_normal_f32 at counter offset + e*n_neg + d: the same distribution as
+ * the reference (its Python / numpy RNG stream cannot be reproduced), the same numbers as
+ * oracle/c/oracle.c:or_sample_negatives.  Candidate items are first_item .. num_item-1 (first_item = 1 for the
+ * sequence loaders' +1 shift).  A user with no candidate, or out of range, gets -1 (the step kernels skip it). */
+int32_t dr_sample_negatives_i32(const int32_t* train_ptr, const int32_t* train_idx, const int32_t* users, int64_t n,
+                                int32_t n_neg, int64_t num_user, int64_t num_item, int64_t first_item,
+                                uint64_t seed, uint64_t offset, int32_t* out, void* stream);
+
 /* ---- multi-GPU routing helper (no counterpart in the reference, which is single-device) ----
  * Stable bucketing of n small keys in [0, nkeys), nkeys <= 256 (key = owning rank of a looked-up row):
  * order[x] = position of the x-th element in ascending key order, ties in input order; counts[b] = number of

@@ -168,3 +168,43 @@ void or_gather(const float* table, int64_t rows, int k, const int32_t* ids, int6
         else memcpy(out + e * k, table + (int64_t)ids[e] * k, sizeof(float) * (size_t)k);
     }
 }
+
+/* ---- negative sampler: restates bprmf.py:126-133,175-181 (uniform draw from all items minus the user's
+ * train items) with the counter-based generator in place of numpy's stream; checker for
+ * dr_sample_negatives_i32.  Deliberately the plain formulation: build the candidate list, index it. ---- */
+static uint32_t or_counter_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+void or_sample_negatives(const int32_t* train_ptr, const int32_t* train_idx, const int32_t* users, int64_t n,
+                         int32_t n_neg, int64_t num_user, int64_t num_item, int64_t first_item, uint64_t seed,
+                         uint64_t offset, int32_t* out) {
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (size_t)(num_item > 0 ? num_item : 1));
+    for (int64_t e = 0; e < n; ++e) {
+        const int64_t u = users[e];
+        int64_t cnt = 0;
+        if (u >= 0 && u < num_user) {
+            int p = train_ptr[u];
+            const int pe = train_ptr[u + 1];
+            for (int64_t it = first_item; it < num_item; ++it) {      /* neg_items[u], ascending */
+                while (p < pe && train_idx[p] < it) ++p;
+                if (p < pe && train_idx[p] == it) continue;
+                cand[cnt++] = (int32_t)it;
+            }
+        }
+        for (int d = 0; d < n_neg; ++d) {
+            const int64_t x = e * n_neg + d;
+            if (cnt <= 0) {
+                out[x] = -1;
+                continue;
+            }
+            const uint64_t r = or_counter_u32(seed, offset + (uint64_t)x);
+            out[x] = cand[(r * (uint64_t)cnt) >> 32];
+        }
+    }
+    free(cand);
+}

@@ -44,6 +44,16 @@ def init_normal(count, seed, stddev):
     return w
 
 
+def sample_negatives(train_ptr, train_idx, users, num_item, seed, offset=0, n_neg=1, first_item=0):
+    """or_sample_negatives: uniform draws from all items minus the user's train items (bprmf.py:126-133,175-181)."""
+    train_ptr, train_idx, users = _i32(train_ptr), _i32(train_idx), _i32(users)
+    out = np.empty((len(users), n_neg), np.int32)
+    lib().or_sample_negatives(_p(train_ptr), _p(train_idx), _p(users), C.c_int64(len(users)), C.c_int32(n_neg),
+                              C.c_int64(len(train_ptr) - 1), C.c_int64(num_item), C.c_int64(first_item),
+                              C.c_uint64(seed), C.c_uint64(offset), _p(out))
+    return out
+
+
 def pair_dot(A, B, ai, bi):
     A, B, ai, bi = _f32(A), _f32(B), _i32(ai), _i32(bi)
     out = np.empty(len(ai), np.float32)

@@ -402,3 +402,44 @@ def test_nnmf_runs(dev):
     for _ in range(30):
         quiet(m.train, rt)
     assert quiet(m.test, rt.todok())["RMSE"] < before
+
+
+def test_bprmf_device_sampler_and_checkpoint(dev, tmp_path):
+    """sampler="device": the epoch's negatives are dr_sample_negatives_i32 draws (== oracle restatement, never a
+    train item), the step that consumes them matches the oracle; save() / load() round-trips tables and slots."""
+    from deeprec_amd.models.item_ranking.bprmf import BPRMF
+    rng = np.random.default_rng(4)
+    nu, ni, k, B = 40, 60, 16, 96
+    train, test = _toy_data(rng, nu, ni)
+    P0 = (rng.standard_normal((nu, k)) * 0.01).astype(np.float32)
+    Q0 = (rng.standard_normal((ni, k)) * 0.01).astype(np.float32)
+    model = quiet(BPRMF, nu, ni, 0.001, 0.1, 1, B, sampler="device")
+    model.build_network(num_factor=k, P=P0, Q=Q0)
+    quiet(model.prepare_data, train, test)
+    np.random.seed(11)
+    model.train()
+    np.random.seed(11)                                    # replay: permutation, then the epoch's sampler seed
+    idxs = np.random.permutation(model.num_training)
+    seed = int(np.random.randint(0, 2 ** 31 - 1))
+    ur, ir = model.user[idxs], model.item[idxs]
+    csr = train.tocsr()
+    csr.sort_indices()
+    jr = co.sample_negatives(csr.indptr, csr.indices, ur, ni, seed)[:, 0]
+    for e in range(len(ur)):
+        assert jr[e] not in csr.indices[csr.indptr[ur[e]]:csr.indptr[ur[e] + 1]]
+    P, Q = P0.copy(), Q0.copy()
+    sP, sQ = [np.zeros_like(P), np.zeros_like(P)], [np.zeros_like(Q), np.zeros_like(Q)]
+    for b in range(model.total_batch):
+        s = slice(b * B, (b + 1) * B)
+        hp = dict(alpha=float(ro.adam_alpha(0.001, 0.9, 0.999, b + 1)), beta1=0.9, beta2=0.999, eps=1e-7)
+        P, Q, sP, sQ, _, _ = ro.pairwise_step(P, Q, sP, sQ, ur[s], ir[s], jr[s], ro.OPT_ADAM, hp, 0.1, ro.REG_DENSE)
+    np.testing.assert_allclose(model.P.cpu().numpy(), P, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(model.Q.cpu().numpy(), Q, rtol=1e-4, atol=1e-6)
+    path = str(tmp_path / "bprmf.safetensors")
+    model.save(path)
+    other = quiet(BPRMF, nu, ni, 0.001, 0.1, 1, B)
+    other.build_network(num_factor=k)
+    other.load(path)
+    assert torch.equal(other.P, model.P) and torch.equal(other.Q, model.Q)
+    for a, b in zip(other.optimizer.slots_for(other.P), model.optimizer.slots_for(model.P)):
+        assert (a is None and b is None) or torch.equal(a, b)

@@ -579,3 +579,37 @@ def test_bucket_order_is_stable_counting_sort(dev, n, nkeys):
     order, counts = K.bucket_order(T(keys, dev), nkeys)
     assert np.array_equal(N(order), np.argsort(keys, kind="stable").astype(np.int32))
     assert np.array_equal(N(counts), np.bincount(keys, minlength=nkeys))
+
+
+# ------------------------------------------------------------------ negative sampler
+@pytest.mark.parametrize("first", [0, 1])
+def test_sample_negatives_matches_oracle(dev, first):
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(31 + first)
+    nu, ni = 300, 517
+    lists = [np.sort(rng.choice(np.arange(first, ni), rng.integers(0, 60), replace=False)) for _ in range(nu)]
+    lists[5] = np.arange(first, ni)                    # a user who has seen everything -> -1
+    lists[6] = np.arange(first, ni - 1)                # exactly one candidate left
+    tp, ti = _csr(lists)
+    users = rng.integers(0, nu, 4096).astype(np.int32)
+    users[:8] = [5, 6, 5, 6, 0, 1, 2, 3]
+    got = N(K.sample_negatives(T(tp, dev), T(ti, dev), T(users, dev), ni, seed=77, offset=1000, n_neg=3, first_item=first))
+    want = co.sample_negatives(tp, ti, users, ni, 77, 1000, 3, first)
+    assert np.array_equal(got, want)
+    assert (got[users == 5] == -1).all() and (got[users == 6] == ni - 1).all()
+    for e in range(0, 4096, 37):                       # never a train item, always in range
+        ok = got[e][got[e] >= 0]
+        assert not np.isin(ok, lists[users[e]]).any() and (ok >= first).all() and (ok < ni).all()
+
+
+def test_sample_negatives_is_uniform_over_unseen(dev):
+    from deeprec_amd import kernels as K
+    ni = 64
+    seen = np.arange(0, ni, 2, dtype=np.int32)         # even items seen -> 32 odd candidates
+    tp, ti = _csr([seen])
+    n = 1 << 18
+    got = N(K.sample_negatives(T(tp, dev), T(ti, dev), T(np.zeros(n, np.int32), dev), ni, seed=3))[:, 0]
+    cnt = np.bincount(got, minlength=ni)
+    assert (cnt[::2] == 0).all()
+    exp = n / 32
+    assert np.abs(cnt[1::2] - exp).max() < 6 * np.sqrt(exp)

@@ -95,3 +95,31 @@ def test_shard_helpers():
     assert t.local_rows == 3          # rows 1, 5, 9
     t3 = sh.ShardedTable(10, 2, 4, 3, "cpu")
     assert t3.local_rows == 2         # rows 3, 7
+
+
+@pytest.mark.parametrize("w_save,w_load", [(2, 3), (3, 1), (1, 4), (4, 4)])
+def test_sharded_checkpoint_reshards(tmp_path, w_save, w_load):
+    """save at one world size, load at another: every global row (table and slots) comes back where
+    owner = row % world says it lives."""
+    from deeprec_amd import sharding as sh
+    rng = np.random.default_rng(w_save * 10 + w_load)
+    rows = {"P": 103, "Q": 41}
+    k = 6
+    full = {n: torch.from_numpy(rng.standard_normal((r, k)).astype(np.float32)) for n, r in rows.items()}
+    slot = {n: [torch.from_numpy(rng.standard_normal((r, k)).astype(np.float32)) for _ in range(2)] for n, r in rows.items()}
+    prefix = str(tmp_path / "ckpt")
+    for r in range(w_save):
+        tabs = {}
+        for n in rows:
+            t = sh.ShardedTable(rows[n], k, w_save, r, "cpu", 2)
+            t.load_global(full[n])
+            for j in range(2):
+                t.slots[j].copy_(slot[n][j][r::w_save])
+            tabs[n] = t
+        sh.save_sharded(prefix, tabs)
+    for r in range(w_load):
+        got = sh.load_sharded(prefix, ["P", "Q"], w_load, r, "cpu")
+        for n in rows:
+            assert torch.equal(got[n].w, full[n][r::w_load])
+            for j in range(2):
+                assert torch.equal(got[n].slots[j], slot[n][j][r::w_load])
