@@ -51,6 +51,7 @@ struct ScoreArgs {
     float* part_v;       // [S, Nu, K]
     int32_t* part_i;     // [S, Nu, K]
     float* out;          // [Nu, Ni] (matrix mode)
+    const int32_t* mode_flag;  // device word: 0 = every user has <= 1 held-out item (score_kernel_t1 runs), 1 = general
 };
 
 __device__ __forceinline__ float score_epilogue(float acc, float cdot, const float* uadd, const float* iadd, int64_t u,
@@ -424,14 +425,22 @@ __global__ __launch_bounds__(256) void score_kernel_anyk(ScoreArgs a) {
 // whole item stream (lane l holds U[row l%32][2j + l/32], j < KS); only item tiles go through LDS, and the
 // next tile's global loads are issued a whole phase before they are needed. ----
 //
-// Thread -> chunk element mapping, all compile-time: W floats per element (float4 when k % 4 == 0), CPT
+// Item tile in LDS for the register kernels: row stride LDP floats (16-byte aligned rows), and inside each group of
+// 8 k the even k first, then the odd k.  MFMA lane (n, h) needs B[n][2j + h] for consecutive j: with this layout
+// four consecutive k-steps are ONE ds_read_b128 at slot 8*(j/4) + 4h, and a thread that fetched 8 consecutive k
+// of a row (two float4) stores them as two ds_write_b128.  The permutation only moves values inside LDS: every
+// MFMA still receives k = 2j + h, so the accumulation order -- and every bit of the result -- is unchanged.
+constexpr int LDP = KC + 4;
+__device__ __forceinline__ constexpr int kpos(int c) { return (c & ~7) + ((c & 1) << 2) + ((c & 7) >> 1); }
+
+// Thread -> chunk element mapping, all compile-time: W floats per element (8 when k % 8 == 0, else 1), CPT
 // elements per row (power of two covering the widest chunk of this instantiation), thread th owns column
 // element th % CPT of rows th / CPT + q * RPP.  Global addresses are (uniform tile base) + (per-thread
 // constant 32-bit offset); LDS addresses are (per-thread constant) + immediates.
 template <int KS, bool VEC>
 struct Geo {
-    static constexpr int W = VEC ? 4 : 1;
-    static constexpr int CPT = VEC ? (KS >= 64 ? 32 : 16) : (KS >= 64 ? 128 : 64);
+    static constexpr int W = VEC ? 8 : 1;
+    static constexpr int CPT = VEC ? (KS >= 64 ? 16 : 8) : (KS >= 64 ? 128 : 64);
     static constexpr int RPP = 256 / CPT;
     static constexpr int PASSES = TI / RPP;
     static constexpr int NPRE = PASSES * W;
@@ -442,77 +451,79 @@ __device__ __forceinline__ void prefetch_chunk(float (&pre)[N], const float* __r
                                                int k, int kc0, int r0, int gc) {
     using G = Geo<KS, VEC>;
     const char* tile = reinterpret_cast<const char*>(I) + (i0 * k + kc0) * 4;  // uniform
-    if (i0 + TI <= Ni) {
-        const uint32_t voff = ((uint32_t)r0 * (uint32_t)k + (uint32_t)gc * G::W) * 4u;
+    const bool full = i0 + TI <= Ni;
+    const int rmax = full ? TI : (int)(Ni - 1 - i0);   // ragged last tile: rows beyond Ni re-read the last valid
+    const uint32_t voff = ((uint32_t)r0 * (uint32_t)k + (uint32_t)gc * G::W) * 4u;  // row (never looked at)
 #pragma unroll
-        for (int q = 0; q < G::PASSES; ++q) {
-            const char* p = tile + (int64_t)(q * G::RPP) * k * 4 + voff;
-            if (VEC) {
-                const float4 v = *reinterpret_cast<const float4*>(p);
-                pre[4 * q] = v.x; pre[4 * q + 1] = v.y; pre[4 * q + 2] = v.z; pre[4 * q + 3] = v.w;
-            } else {
-                pre[q] = *reinterpret_cast<const float*>(p);
-            }
-        }
-    } else {  // ragged last tile: rows beyond Ni re-read the last valid row (their scores are never looked at)
-        const int rmax = (int)(Ni - 1 - i0);
-#pragma unroll
-        for (int q = 0; q < G::PASSES; ++q) {
+    for (int q = 0; q < G::PASSES; ++q) {
+        const char* p;
+        if (full) {
+            p = tile + (int64_t)(q * G::RPP) * k * 4 + voff;
+        } else {
             int r = r0 + q * G::RPP;
             r = r < rmax ? r : rmax;
-            const char* p = tile + ((int64_t)r * k + gc * G::W) * 4;
-            if (VEC) {
-                const float4 v = *reinterpret_cast<const float4*>(p);
-                pre[4 * q] = v.x; pre[4 * q + 1] = v.y; pre[4 * q + 2] = v.z; pre[4 * q + 3] = v.w;
-            } else {
-                pre[q] = *reinterpret_cast<const float*>(p);
-            }
+            p = tile + ((int64_t)r * k + gc * G::W) * 4;
+        }
+        if (VEC) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p);
+            const float4 v1 = *reinterpret_cast<const float4*>(p + 16);
+            pre[8 * q] = v0.x; pre[8 * q + 1] = v0.y; pre[8 * q + 2] = v0.z; pre[8 * q + 3] = v0.w;
+            pre[8 * q + 4] = v1.x; pre[8 * q + 5] = v1.y; pre[8 * q + 6] = v1.z; pre[8 * q + 7] = v1.w;
+        } else {
+            pre[q] = *reinterpret_cast<const float*>(p);
         }
     }
 }
 
+// d = sI + r0 * LDP + (VEC ? g * 8 : kpos(g))
 template <int KS, bool VEC, int N>
 __device__ __forceinline__ void store_chunk(float* __restrict__ d, const float (&pre)[N]) {
     using G = Geo<KS, VEC>;
 #pragma unroll
     for (int q = 0; q < G::PASSES; ++q) {
-#pragma unroll
-        for (int j = 0; j < G::W; ++j) d[q * G::RPP * LDK + j] = pre[q * G::W + j];
+        if (VEC) {
+            float4* o = reinterpret_cast<float4*>(d + q * G::RPP * LDP);
+            o[0] = make_float4(pre[8 * q], pre[8 * q + 2], pre[8 * q + 4], pre[8 * q + 6]);      // even k
+            o[1] = make_float4(pre[8 * q + 1], pre[8 * q + 3], pre[8 * q + 5], pre[8 * q + 7]);  // odd k
+        } else {
+            d[q * G::RPP * LDP] = pre[q];
+        }
     }
 }
 
-// 8 * NG MFMAs of one k-chunk: B operands come from LDS in groups of 8 k-steps, each group's reads issued one
-// group ahead of its MFMAs.  ng = number of groups that hold data (the rest of the chunk is skipped).
+// 8 * NG MFMAs of one k-chunk.  pb = sI + column * LDP + 4 * (lane >> 5); B operands arrive as one float4 per four
+// k-steps, each group of 8 k-steps read one group ahead of its MFMAs.  ng = number of groups that hold data.
 template <int NG>
 __device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const float* __restrict__ pb, int ng) {
-    float b[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) b[0][j] = pb[2 * j];
+    float4 b[2][2];
+    b[0][0] = *reinterpret_cast<const float4*>(pb);
+    b[0][1] = *reinterpret_cast<const float4*>(pb + 8);
+#define DR_MFMA_GROUP(gq)                                                                                          \
+    {                                                                                                              \
+        if ((gq) + 1 < NG) {                                                                                       \
+            b[((gq) + 1) & 1][0] = *reinterpret_cast<const float4*>(pb + ((gq) + 1) * 16);                         \
+            b[((gq) + 1) & 1][1] = *reinterpret_cast<const float4*>(pb + ((gq) + 1) * 16 + 8);                     \
+        }                                                                                                          \
+        const float4 x = b[(gq) & 1][0], y = b[(gq) & 1][1];                                                       \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 0], x.x, acc, 0, 0, 0);                         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 1], x.y, acc, 0, 0, 0);                         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 2], x.z, acc, 0, 0, 0);                         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 3], x.w, acc, 0, 0, 0);                         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 4], y.x, acc, 0, 0, 0);                         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 5], y.y, acc, 0, 0, 0);                         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 6], y.z, acc, 0, 0, 0);                         \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 7], y.w, acc, 0, 0, 0);                         \
+    }
     if (ng == NG) {  // full chunk: one straight-line block
 #pragma unroll
-        for (int gq = 0; gq < NG; ++gq) {
-            if (gq + 1 < NG) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) b[(gq + 1) & 1][j] = pb[((gq + 1) * 8 + j) * 2];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[gq * 8 + j], b[gq & 1][j], acc, 0, 0, 0);
-        }
+        for (int gq = 0; gq < NG; ++gq) DR_MFMA_GROUP(gq)
     } else {
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
-            if (gq < ng) {  // uniform
-                if (gq + 1 < NG) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) b[(gq + 1) & 1][j] = pb[((gq + 1) * 8 + j) * 2];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[gq * 8 + j], b[gq & 1][j], acc, 0, 0, 0);
-            }
+            if (gq < ng) DR_MFMA_GROUP(gq)  // uniform
         }
     }
+#undef DR_MFMA_GROUP
 }
 
 template <int KS>
@@ -531,12 +542,13 @@ template <bool MATRIX, int KS, bool VEC>
 __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
     using G = Geo<KS, VEC>;
     extern __shared__ __align__(16) float smem[];
-    float* sI = smem;  // [TI][LDK]
+    float* sI = smem;  // [TI][LDP], k-permuted (see LDP)
     Sel z;
-    z.base = smem + TI * LDK;
+    z.base = smem + TI * LDP;
     constexpr int NCH = (2 * KS + KC - 1) / KC;      // item chunks per tile (compile-time upper bound)
     constexpr int JPC = KS < KC / 2 ? KS : KC / 2;   // k-steps per chunk
 
+    if (!MATRIX && a.mode_flag && *a.mode_flag == 0) return;  // score_kernel_t1 handles this call
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wu = wave >> 1, wi = wave & 1;
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
     float areg[KS];
     load_areg<KS>(areg, a, u0, wu, lane);
     // columns that no chunk store touches must read as zero in the MFMA loop (groups of 16 k)
-    for (int e = tid; e < TI * LDK; e += 256) sI[e] = 0.0f;
+    for (int e = tid; e < TI * LDP; e += 256) sI[e] = 0.0f;
     if (!MATRIX) sel_init(z, a, u0, t_begin, tid);
     const bool affine = a.uadd || a.iadd || a.cdot != 1.0f;
     float ua[16];
@@ -563,8 +575,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
     const bool live0 = g * G::W < kc_first;
     const bool live1 = NCH > 1 && g * G::W < k - KC;
     const int gc0 = live0 ? g : 0, gc1 = live1 ? g : 0;
-    float* dst = sI + r0 * LDK + g * G::W;
-    const float* pb = sI + mycol * LDK + (lane >> 5);
+    float* dst = sI + r0 * LDP + (VEC ? g * 8 : kpos(g));
+    const float* pb = sI + mycol * LDP + 4 * (lane >> 5);
 
     float pre[G::NPRE];
     float ia_next = -0.0f;
@@ -608,6 +620,275 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
         __syncthreads();
         sel_finish(z, a, u0, split, tid);
     }
+}
+
+// ---- k <= 128 and at most ONE held-out item per user (leave-one-out evaluation, the C4 shape): the selection
+// runs on the accumulators in registers.  fp32 MFMA shares the SIMD's vector pipe with ordinary VALU work, so
+// what the selection costs is its instruction count: here a tile costs, per lane, 16 compares against the row's
+// K-th best, 16 compare-and-count against the row's held-out score and 16 tie tests -- no score tile, no LDS
+// round trip, two barriers per tile.  A score that beats the K-th best (rare after the first tiles) is
+// written to the LDS score tile with its bit in the row's candidate word, and the row's owner lane folds it
+// into the sorted list at the next barrier.  Masked (train) items of a tile are published by the owners as
+// 64-bit row words with a block-wide "any" flag, so tiles without masked items (most) skip the patch.
+// LDS (floats, after the item tile):
+constexpr int T1_SS = 0;                          // [TU][LDS_S] candidate scores (sparse)
+constexpr int T1_TAU = T1_SS + TU * LDS_S;        // [TU]
+constexpr int T1_CANDW = T1_TAU + TU;             // [TU] u64
+constexpr int T1_MASKW = T1_CANDW + 2 * TU;       // [TU] u64
+constexpr int T1_TSC = T1_MASKW + 2 * TU;         // [TU] held-out score (+inf: none)
+constexpr int T1_TID = T1_TSC + TU;               // [TU] held-out item id (-1: none)
+constexpr int T1_TCNT = T1_TID + TU;              // [TU] rank counters
+constexpr int T1_MISC = T1_TCNT + TU;             // [0] epoch of tau, [1..2] any-mask flags (tile parity)
+constexpr int T1_TOPV = T1_MISC + 4;              // [TU][K] scores, then [TU][K] ids
+static_assert((T1_CANDW % 2) == 0 && (T1_MASKW % 2) == 0 && (T1_TOPV % 4) == 0, "LDS alignment");
+
+template <int KS, bool VEC>
+__global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
+    using G = Geo<KS, VEC>;
+    static_assert(KS <= KC / 2, "one k-chunk per tile");
+    if (*a.mode_flag != 0) return;  // some user has several held-out items: score_kernel handles this call
+    extern __shared__ __align__(16) float smem[];
+    float* sI = smem;  // [TI][LDP], k-permuted (see LDP)
+    float* base = smem + TI * LDP;
+    float* sS = base + T1_SS;
+    float* tau = base + T1_TAU;
+    unsigned long long* candw = reinterpret_cast<unsigned long long*>(base + T1_CANDW);
+    unsigned long long* maskw = reinterpret_cast<unsigned long long*>(base + T1_MASKW);
+    float* tsc = base + T1_TSC;
+    int* tidl = reinterpret_cast<int*>(base + T1_TID);
+    int* tcnt = reinterpret_cast<int*>(base + T1_TCNT);
+    int* misc = reinterpret_cast<int*>(base + T1_MISC);
+    const int K = a.K;
+    float* topv = base + T1_TOPV;
+    int* topi = reinterpret_cast<int*>(base + T1_TOPV + TU * K);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wu = wave >> 1, wi = wave & 1;
+    const int64_t u0 = (int64_t)blockIdx.x * TU;
+    const int split = blockIdx.y;
+    const int t_begin = split * a.tiles_per_split;
+    int t_end = t_begin + a.tiles_per_split;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    const int k = a.k;
+
+    float areg[KS];
+    load_areg<KS>(areg, a, u0, wu, lane);
+    for (int e = tid; e < TI * LDP; e += 256) sI[e] = 0.0f;
+    for (int e = tid; e < TU * K; e += 256) {
+        topv[e] = -INFINITY;
+        topi[e] = 0x7fffffff;
+    }
+    // row owner = lane th % 4 == 0 of row th / 4: train cursor (two items cached ahead) in registers
+    const int orow = tid >> 2;
+    const int64_t ou = u0 + orow;
+    const bool owner = (tid & 3) == 0 && ou < a.Nu;
+    int cur = 0, cur_end = 0, nxt = 0x7fffffff, nxt2 = 0x7fffffff;
+    if (tid < TU) {
+        const int64_t u = u0 + tid;
+        tau[tid] = (u < a.Nu) ? __builtin_nanf("") : INFINITY;
+        candw[tid] = 0ull;
+        maskw[tid] = 0ull;
+        tcnt[tid] = 0;
+        float sc = INFINITY;
+        int id = -1;
+        if (a.tgt_ptr && u < a.Nu) {
+            const int p = a.tgt_ptr[u];
+            if (a.tgt_ptr[u + 1] > p && !a.tgt_masked[p]) {
+                sc = a.tgt_score[p];
+                id = a.tgt_idx[p];
+            }
+        }
+        tsc[tid] = sc;
+        tidl[tid] = id;
+    }
+    if (tid < 4) misc[tid] = 0;
+    if (owner && a.train_ptr) {
+        cur = a.train_ptr[ou];
+        cur_end = a.train_ptr[ou + 1];
+        const int first = t_begin * TI;
+        int lo = cur, hi = cur_end;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (a.train_idx[mid] < first) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+        nxt = cur < cur_end ? a.train_idx[cur] : 0x7fffffff;
+        nxt2 = cur + 1 < cur_end ? a.train_idx[cur + 1] : 0x7fffffff;
+    }
+    const bool affine = a.uadd || a.iadd || a.cdot != 1.0f;
+    float ua[16];
+    load_uadd(ua, a, u0, wu, lane);
+    const int mycol = wi * 32 + (lane & 31);
+    const int rbase = wu * 32 + 4 * (lane >> 5);   // row of accumulator element r = rbase + (r&3) + 8*(r>>2)
+
+    const int g = tid % G::CPT, r0 = tid / G::CPT;
+    const bool live0 = g * G::W < k;
+    const int gc0 = live0 ? g : 0;
+    float* dst = sI + r0 * LDP + (VEC ? g * 8 : kpos(g));
+    const float* pb = sI + mycol * LDP + 4 * (lane >> 5);
+
+    float pre[G::NPRE];
+    float ia_next = -0.0f;
+    if (t_begin < t_end) {
+        prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, (int64_t)t_begin * TI, a.Ni, k, 0, r0, gc0);
+        ia_next = load_iadd(a, (int64_t)t_begin * TI + mycol);
+    }
+    __syncthreads();
+    float tauR[16], stR[16];
+    int cnt[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        tauR[r] = tau[row];
+        stR[r] = tsc[row];
+        cnt[r] = 0;
+    }
+    int my_epoch = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no wait inside the loop is inherited from the prologue
+
+    for (int t = t_begin; t <= t_end; ++t) {   // iteration t_end only folds the last tile's candidates
+        const int64_t i0 = (int64_t)t * TI;
+        __syncthreads();  // A: tile t-1's candidates are visible, every wave is done with the item tile in LDS
+        if (owner) {
+            unsigned long long m = candw[orow];
+            if (m) {  // fold tile t-1's candidates of this row into its sorted list
+                candw[orow] = 0ull;
+                const float* srow = sS + orow * LDS_S;
+                float* tv = topv + orow * K;
+                int* ti = topi + orow * K;
+                while (m) {
+                    const int c = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float sc = srow[c];
+                    const int item = (int)(i0 - TI + c);
+                    if (beats(sc, item, tv[K - 1], ti[K - 1])) {
+                        int p = K - 1;
+                        while (p > 0 && beats(sc, item, tv[p - 1], ti[p - 1])) {
+                            tv[p] = tv[p - 1];
+                            ti[p] = ti[p - 1];
+                            --p;
+                        }
+                        tv[p] = sc;
+                        ti[p] = item;
+                    }
+                }
+                if (ti[K - 1] != 0x7fffffff && !(tv[K - 1] == tau[orow])) {
+                    tau[orow] = tv[K - 1];
+                    atomicAdd(&misc[0], 1);
+                }
+            }
+        }
+        if (t == t_end) break;
+        if (owner) {  // masked (train) items of tile t for this row
+            unsigned long long m = 0ull;
+            const int hi = (int)i0 + TI;
+            if (nxt < hi) {
+                m |= 1ull << (nxt - (int)i0);
+                ++cur;
+                nxt = nxt2;
+                nxt2 = cur + 1 < cur_end ? a.train_idx[cur + 1] : 0x7fffffff;
+                while (nxt < hi) {
+                    m |= 1ull << (nxt - (int)i0);
+                    ++cur;
+                    nxt = nxt2;
+                    nxt2 = cur + 1 < cur_end ? a.train_idx[cur + 1] : 0x7fffffff;
+                }
+                atomicOr(&misc[1 + (t & 1)], 1);
+            }
+            maskw[orow] = m;
+        }
+        if (tid == 0) misc[1 + ((t + 1) & 1)] = 0;
+        if (live0) store_chunk<KS, VEC, G::NPRE>(dst, pre);
+        const float ia = ia_next;
+        __syncthreads();  // B
+        if (t + 1 < t_end) {
+            prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, i0 + TI, a.Ni, k, 0, r0, gc0);
+            ia_next = load_iadd(a, i0 + TI + mycol);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        mfma_chunk<KS / 8>(acc, areg, pb, (k + 15) >> 4);
+        if (affine) {
+            const float cd = a.cdot;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sc = cd * acc[r];
+                sc = sc + ua[r];
+                acc[r] = sc + ia;
+            }
+        }
+        // entries that must be looked at by nobody: masked train items, columns beyond the catalog
+        unsigned dead = 0u;
+        const int nc = (a.Ni - i0 < TI) ? (int)(a.Ni - i0) : TI;
+        if (misc[1 + (t & 1)] != 0 || nc != TI) {
+            if (mycol >= nc) dead = 0xffffu;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long m = maskw[rbase + (r & 3) + 8 * (r >> 2)];
+                dead |= (unsigned)((m >> mycol) & 1ull) << r;
+            }
+        }
+        const int ep = misc[0];
+        if (ep != my_epoch) {
+            my_epoch = ep;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tauR[r] = tau[rbase + (r & 3) + 8 * (r >> 2)];
+        }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sc = acc[r];
+            any |= !(sc <= tauR[r]);      // beats the K-th best, or the list is not full yet (tau = NaN)
+            any |= (sc == stR[r]);        // tie with the held-out item: decided by item id
+        }
+        if (dead == 0u && !any) {         // the usual tile: count and go on
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnt[r] += (acc[r] > stR[r]) ? 1 : 0;
+        } else {
+            const int item = (int)i0 + mycol;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((dead >> r) & 1u) continue;
+                const float sc = acc[r];
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (sc > stR[r]) {
+                    ++cnt[r];
+                } else if (sc == stR[r]) {
+                    const int ct = tidl[row];
+                    if (ct >= 0 && item < ct) ++cnt[r];
+                }
+                if (!(sc <= tauR[r]) && sc == sc) {
+                    sS[row * LDS_S + mycol] = sc;
+                    atomicOr(&candw[row], 1ull << mycol);
+                }
+            }
+        }
+    }
+    // per-lane rank counts -> rows -> global
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (cnt[r]) atomicAdd(&tcnt[rbase + (r & 3) + 8 * (r >> 2)], cnt[r]);
+    __syncthreads();
+    for (int e = tid; e < TU * K; e += 256) {
+        const int r = e / K, c = e - r * K;
+        const int64_t u = u0 + r;
+        if (u < a.Nu) {
+            const int64_t o = ((int64_t)split * a.Nu + u) * K + c;
+            a.part_v[o] = topv[e];
+            a.part_i[o] = topi[e];
+        }
+    }
+    if (a.tgt_ptr && tid < TU && u0 + tid < a.Nu && tcnt[tid] != 0 && tidl[tid] >= 0)
+        atomicAdd(a.tgt_rank + a.tgt_ptr[u0 + tid], tcnt[tid]);
+}
+
+// 1 in *flag when some user has more than one held-out item (flag is zeroed before the launch)
+__global__ __launch_bounds__(256) void target_mode_kernel(const int32_t* __restrict__ tgt_ptr, int64_t Nu,
+                                                          int32_t* __restrict__ flag) {
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < Nu; u += (int64_t)gridDim.x * 256)
+        if (tgt_ptr[u + 1] - tgt_ptr[u] > 1) *flag = 1;
 }
 
 // S-way merge of the per-split sorted candidate lists
@@ -820,7 +1101,7 @@ __global__ __launch_bounds__(256) void topk_rank_matrix_kernel(const float* __re
 }
 
 struct TopkLayout {
-    int64_t uadd, iadd, ucat, icat, tgt_score, tgt_masked, part_v, part_i, total;
+    int64_t uadd, iadd, ucat, icat, tgt_score, tgt_masked, part_v, part_i, mode, total;
     int S, ntiles, tiles_per_split;
 };
 
@@ -850,12 +1131,13 @@ static void topk_layout(int64_t Nu, int64_t Ni, int k, int K, int64_t ntgt, int 
     L->tgt_masked = take(ntgt * 4);
     L->part_v = take((int64_t)L->S * Nu * K * 4);
     L->part_i = take((int64_t)L->S * Nu * K * 4);
+    L->mode = take(256);
     L->total = off;
 }
 
 static size_t sel_area_floats(int K) { return (size_t)TOPV_OFF + (size_t)2 * TU * K; }
 static size_t score_smem_bytes(int K, bool anyk) {
-    return ((size_t)(anyk ? 2 : 1) * TI * LDK + sel_area_floats(K)) * 4;
+    return ((anyk ? (size_t)2 * TI * LDK : (size_t)TI * LDP) + sel_area_floats(K)) * 4;
 }
 
 template <bool MATRIX, int KS, bool VEC>
@@ -868,10 +1150,26 @@ static int launch_score_regs(const ScoreArgs& a, dim3 grid, hipStream_t st) {
     return DR_OK;
 }
 
+static size_t t1_smem_bytes(int K) { return ((size_t)TI * LDP + T1_TOPV + (size_t)2 * TU * K) * 4; }
+
+template <int KS, bool VEC>
+static int launch_score_t1_k(const ScoreArgs& a, dim3 grid, hipStream_t st) {
+    const size_t smem = t1_smem_bytes(a.K);
+    DR_HIP(hipFuncSetAttribute((const void*)score_kernel_t1<KS, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DR_LAUNCH((score_kernel_t1<KS, VEC>), grid, dim3(256), smem, st, a);
+    DR_CHECK_LAUNCH("score_kernel_t1");
+    return DR_OK;
+}
+static int launch_score_t1(const ScoreArgs& a, dim3 grid, hipStream_t st) {
+    const bool vec = (a.k & 7) == 0;  // rows fetched as pairs of float4
+    if (a.k <= 64) return vec ? launch_score_t1_k<32, true>(a, grid, st) : launch_score_t1_k<32, false>(a, grid, st);
+    return vec ? launch_score_t1_k<64, true>(a, grid, st) : launch_score_t1_k<64, false>(a, grid, st);
+}
+
 // grid = (64-user panels, item splits)
 template <bool MATRIX>
 static int launch_score(const ScoreArgs& a, dim3 grid, hipStream_t st) {
-    const bool vec = (a.k & 3) == 0;
+    const bool vec = (a.k & 7) == 0;  // rows fetched as pairs of float4
     if (a.k <= 64) return vec ? launch_score_regs<MATRIX, 32, true>(a, grid, st) : launch_score_regs<MATRIX, 32, false>(a, grid, st);
     if (a.k <= 128) return vec ? launch_score_regs<MATRIX, 64, true>(a, grid, st) : launch_score_regs<MATRIX, 64, false>(a, grid, st);
     if (a.k <= 256) return vec ? launch_score_regs<MATRIX, 128, true>(a, grid, st) : launch_score_regs<MATRIX, 128, false>(a, grid, st);
@@ -993,8 +1291,26 @@ extern "C" int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu
     }
     const int64_t panels = (Nu + TU - 1) / TU;
     DR_REQUIRE(panels < (1ll << 31), "dr_score_topk_f32: too many user panels");
-    rc = launch_score<false>(a, dim3((unsigned)panels, (unsigned)L.S), st);
-    if (rc != DR_OK) return rc;
+    const dim3 grid((unsigned)panels, (unsigned)L.S);
+    // k <= 128: the register-selection kernel serves calls in which no user has more than one held-out item; the
+    // general kernel the others.  Which it is is a device-side fact (the target CSR), so both are enqueued and
+    // the one not in charge returns at once.
+    const bool t1 = a.k <= 128 && n_targets <= Nu && getenv("DR_SCORE_NO_T1") == nullptr;
+    if (t1) {
+        int32_t* flag = (int32_t*)(base + L.mode);
+        DR_HIP(hipMemsetAsync(flag, 0, 4, st));
+        a.mode_flag = flag;
+        if (n_targets > 0) {
+            DR_LAUNCH(target_mode_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, tgt_ptr, Nu, flag);
+            DR_CHECK_LAUNCH("target_mode_kernel");
+        }
+        rc = launch_score_t1(a, grid, st);
+        if (rc != DR_OK) return rc;
+    }
+    if (!t1 || n_targets > 0) {   // (with t1 and no targets at all the register kernel is certainly in charge)
+        rc = launch_score<false>(a, grid, st);
+        if (rc != DR_OK) return rc;
+    }
     DR_LAUNCH(topk_merge_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, a.part_v, a.part_i, L.S, Nu, K,
                        topk_idx, topk_score);
     DR_CHECK_LAUNCH("topk_merge_kernel");

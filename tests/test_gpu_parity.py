@@ -448,6 +448,46 @@ def test_score_topk_dot_exact(dev, Nu, Ni, k, K_, ntgt):
     assert np.array_equal(pd.view(np.uint32), scores[a, b].view(np.uint32))
 
 
+@pytest.mark.parametrize("Nu,Ni,k,K_,kind", [(300, 2500, 128, 10, 0), (130, 1000, 64, 10, 0), (70, 1700, 30, 50, 0),
+                                             (200, 1683, 96, 20, 1), (65, 129, 8, 5, 0), (100, 900, 64, 10, 2)])
+def test_score_topk_leave_one_out(dev, Nu, Ni, k, K_, kind):
+    """At most one held-out item per user (k <= 128): the register-selection kernel (score_kernel_t1) is in
+    charge -- same exact top-K, scores and ranks; masked train items, a masked held-out item (rank -1), users
+    without one, forced score ties with the held-out item, ragged last tile, item bias."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(Nu * 7 + k)
+    U, I, train, _ = _eval_case(rng, Nu, Ni, k, min(40, Ni // 3), 0, std=0.3 if kind == 0 else 0.1)
+    U2 = (rng.standard_normal((Nu, k)) * 0.1).astype(np.float32)
+    I2 = (rng.standard_normal((Ni, k)) * 0.1).astype(np.float32)
+    I2[Ni // 3] = I2[Ni // 5]
+    I2[Ni // 2] = I2[Ni // 5]
+    tgt = []
+    for u in range(Nu):
+        if u % 5 == 4:
+            tgt.append(np.zeros(0, np.int64))                       # no held-out item
+        elif u % 7 == 0 and len(train[u]):
+            tgt.append(train[u][:1])                                # held-out item is a train item -> rank -1
+        elif u % 3 == 0:
+            tgt.append(np.array([(Ni // 3, Ni // 2, Ni // 5)[u % 9 // 3]]))   # one of the three tied items
+        else:
+            tgt.append(rng.integers(0, Ni, 1))
+    bias = rng.standard_normal(Ni).astype(np.float32) if kind == 0 and Nu % 2 == 0 else None
+    if bias is not None:
+        bias[Ni // 3] = bias[Ni // 2] = bias[Ni // 5]
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    kw = dict(U2=T(U2, dev), I2=T(I2, dev), alpha=0.2) if kind == 2 else {}
+    if bias is not None:
+        kw["item_bias"] = T(bias, dev)
+    idx, val, rank = K.score_topk(T(U, dev), T(I, dev), K_, score_kind=kind, train=(T(tp, dev), T(ti, dev)),
+                                  targets=(T(gp, dev), T(gi, dev)), **kw)
+    scores = co.score_matrix(U, I, kind, U2 if kind == 2 else None, I2 if kind == 2 else None, 0.2, bias=bias)
+    _check_selection(scores, train, tgt, K_, N(idx), N(val), N(rank))
+    # no targets at all and no train mask: still the register kernel
+    idx2, val2, r2 = K.score_topk(T(U, dev), T(I, dev), K_, score_kind=kind, **kw)
+    _check_selection(scores, [[]] * Nu, [[]] * Nu, K_, N(idx2), N(val2), None)
+
+
 @pytest.mark.parametrize("kind", [1, 2])
 def test_score_topk_distances(dev, kind):
     """CML (cml.py:151-153) and AttRec/PRME (SeqRecMetrics.py:122-123, alpha=0.2) scores."""
