@@ -504,6 +504,7 @@ __device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const
             b[((gq) + 1) & 1][0] = *reinterpret_cast<const float4*>(pb + ((gq) + 1) * 16);                         \
             b[((gq) + 1) & 1][1] = *reinterpret_cast<const float4*>(pb + ((gq) + 1) * 16 + 8);                     \
         }                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0); /* keep the next group's reads ahead of this group's MFMAs */          \
         const float4 x = b[(gq) & 1][0], y = b[(gq) & 1][1];                                                       \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 0], x.x, acc, 0, 0, 0);                         \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 1], x.y, acc, 0, 0, 0);                         \
