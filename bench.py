@@ -239,8 +239,8 @@ def main():
 
 ROCPROF_NAMES = {   # live name -> kernel name in `rocprofv3 --kernel-trace --stats` output (k=128: V=4, 32 lanes/row)
     "bpr_forward_kernel": "dr::bpr_forward_kernel<4, 32>",
-    "seg_update_kernel<item side>": "dr::seg_update_kernel<4, 32, 2>",
-    "seg_update_kernel<user side>": "dr::seg_update_kernel<4, 32, 1>",
+    "seg_update_kernel<item side>": "dr::seg_update_kernel<4, 32, 2, 1>",
+    "seg_update_kernel<user side>": "dr::seg_update_kernel<4, 32, 1, 1>",
     "seg_long_partial_kernel": "dr::seg_long_partial_kernel<4, 32>",
     "seg_long_combine_kernel": "dr::seg_long_combine_kernel<4, 32>",
 }

@@ -292,10 +292,26 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
 }
 
 // gradient total -> destination row (accumulate, or L2 + optimizer application)
-template <int V>
+constexpr int KIND_ANY = -2;  // optimizer kind read from the arguments at run time
+template <int V, int KIND = KIND_ANY>
 __device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, float (&tot)[V]) {
     const int64_t off = (int64_t)r * a.k + c * V;
     float w[V], s0[V], s1[V];
+    if (KIND == DR_OPT_ADAM) {  // the hot instantiation: no switch, all three row loads issued together
+        vload<V>(w, a.table + off);
+        vload<V>(s0, a.slot0 + off);
+        vload<V>(s1, a.slot1 + off);
+        if (a.opt.reg_mode == DR_REG_TOUCHED) {
+#pragma unroll
+            for (int x = 0; x < V; ++x) tot[x] = tot[x] + a.opt.reg * w[x];
+        }
+#pragma unroll
+        for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAM>(w[x], s0[x], s1[x], tot[x], a.opt);
+        vstore<V>(a.slot0 + off, s0);
+        vstore<V>(a.slot1 + off, s1);
+        vstore<V>(a.table + off, w);
+        return;
+    }
     vload<V>(w, a.table + off);
     if (a.kind == KIND_ACC) {
 #pragma unroll
@@ -341,7 +357,7 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, f
 // short segments (<= LONG_SEG contributions, the common case): one sub-wave per segment
 // PART (compile-time copy of a.part) also gives the two launches of a combined two-table plan distinct kernel
 // names in profiler output: <.., 2> is the item-table side of the fused BPR step, <.., 1> the user-table side.
-template <int V, int LPR, int PART>
+template <int V, int LPR, int PART, int KIND>
 __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
     a.opt = resolve(a.opt);
     constexpr int SPB = 256 / LPR;  // segments per block pass
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
                     }
 #pragma unroll
                 for (int x = 0; x < V; ++x) tot[x] = 0.0f + tot[x];
-                apply_row<V>(a, r, c, tot);
+                apply_row<V, KIND>(a, r, c, tot);
             }
         }
     }
@@ -456,14 +472,19 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
     }
 }
 
+template <int V, int LPR, int KIND>
+static void launch_short_k(const SegArgs& a, int grid, hipStream_t st) {
+    if (a.part == 2)
+        DR_LAUNCH_NAMED("seg_update_kernel<item side>", (seg_update_kernel<V, LPR, 2, KIND>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.part == 1)
+        DR_LAUNCH_NAMED("seg_update_kernel<user side>", (seg_update_kernel<V, LPR, 1, KIND>), dim3(grid), dim3(256), 0, st, a);
+    else
+        DR_LAUNCH_NAMED("seg_update_kernel", (seg_update_kernel<V, LPR, 0, KIND>), dim3(grid), dim3(256), 0, st, a);
+}
 template <int V, int LPR>
 static void launch_short(const SegArgs& a, int grid, hipStream_t st) {
-    if (a.part == 2)
-        DR_LAUNCH_NAMED("seg_update_kernel<item side>", (seg_update_kernel<V, LPR, 2>), dim3(grid), dim3(256), 0, st, a);
-    else if (a.part == 1)
-        DR_LAUNCH_NAMED("seg_update_kernel<user side>", (seg_update_kernel<V, LPR, 1>), dim3(grid), dim3(256), 0, st, a);
-    else
-        DR_LAUNCH_NAMED("seg_update_kernel", (seg_update_kernel<V, LPR, 0>), dim3(grid), dim3(256), 0, st, a);
+    if (a.kind == DR_OPT_ADAM) launch_short_k<V, LPR, DR_OPT_ADAM>(a, grid, st);  // fewer registers, one more wave/SIMD
+    else launch_short_k<V, LPR, KIND_ANY>(a, grid, st);
 }
 
 template <int V, int LPR>

@@ -17,8 +17,8 @@ import sys
 
 SHORT = {
     "bpr_forward_kernel": "bpr_forward_kernel",
-    "seg_update_kernel<4, 32, 2>": "seg_update_kernel<item side>",
-    "seg_update_kernel<4, 32, 1>": "seg_update_kernel<user side>",
+    "seg_update_kernel<4, 32, 2, 1>": "seg_update_kernel<item side>",
+    "seg_update_kernel<4, 32, 1, 1>": "seg_update_kernel<user side>",
     "seg_long_partial_kernel": "seg_long_partial_kernel",
     "seg_long_combine_kernel": "seg_long_combine_kernel",
 }
