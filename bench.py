@@ -358,6 +358,25 @@ def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step,
     out["gather"]["users_uniform_10M_4Mrows"] = {"rows": 1 << 22, "avg_ms": t_big, "GBps": gb(1 << 22, t_big),
                                                  "frac_hbm_peak": gb(1 << 22, t_big) / HBM_PEAK_GBPS}
     del big
+    # --- K2 standalone: sorted-segment scatter-add of 4 M gradient rows into a 10 M-row table (uniform ids) ------
+    if sP[1] is not None:
+        n_sc = 1 << 22
+        gen = torch.Generator(device=device)
+        gen.manual_seed(13)
+        sid = torch.randint(0, args.users, (n_sc,), device=device, generator=gen, dtype=torch.int64).to(torch.int32)
+        src = torch.empty((n_sc, k), dtype=torch.float32, device=device)
+        K.init_normal_(src, 3, 0.01)
+        gt = sP[1]                                   # Adam's v of the user table: free to clobber after the timed region
+        plan = K.SegmentPlan(sid, args.users, k_max=k)
+        uq = int(plan.view()[1].numel())
+        t_sc = ev_time(lambda: K.scatter_add(gt, sid, src, plan=plan), 5, stream)
+        t_scp = ev_time(lambda: K.scatter_add(gt, sid, src, plan=K.SegmentPlan(sid, args.users, plan.ws, k_max=k)), 5, stream)
+        b_sc = n_sc * (4 + row) + uq * 2 * row       # ids + grads read, unique rows read + written
+        out["scatter_add"] = {"rows": n_sc, "unique_rows": uq, "avg_ms_planned": t_sc, "GBps_planned": b_sc / (t_sc * 1e-3) / 1e9,
+                              "frac_hbm_peak_planned": b_sc / (t_sc * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "avg_ms_with_plan": t_scp, "GBps_with_plan": b_sc / (t_scp * 1e-3) / 1e9,
+                              "frac_hbm_peak_with_plan": b_sc / (t_scp * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        del src, sid, plan
     # --- negative sampler: one draw per positive from all items minus 100 seen items / user
     ncsr = min(args.users, 1_000_000)
     gen = torch.Generator(device=device)

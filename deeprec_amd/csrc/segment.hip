@@ -297,6 +297,13 @@ template <int V, int KIND = KIND_ANY>
 __device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, float (&tot)[V]) {
     const int64_t off = (int64_t)r * a.k + c * V;
     float w[V], s0[V], s1[V];
+    if (KIND == KIND_ACC) {  // plain lookup backward (dr_scatter_add_sorted_f32)
+        vload<V>(w, a.table + off);
+#pragma unroll
+        for (int x = 0; x < V; ++x) w[x] = w[x] + tot[x];
+        vstore<V>(a.table + off, w);
+        return;
+    }
     if (KIND == DR_OPT_ADAM) {  // the hot instantiation: no switch, all three row loads issued together
         vload<V>(w, a.table + off);
         vload<V>(s0, a.slot0 + off);
@@ -484,6 +491,7 @@ static void launch_short_k(const SegArgs& a, int grid, hipStream_t st) {
 template <int V, int LPR>
 static void launch_short(const SegArgs& a, int grid, hipStream_t st) {
     if (a.kind == DR_OPT_ADAM) launch_short_k<V, LPR, DR_OPT_ADAM>(a, grid, st);  // fewer registers, one more wave/SIMD
+    else if (a.kind == KIND_ACC) launch_short_k<V, LPR, KIND_ACC>(a, grid, st);
     else launch_short_k<V, LPR, KIND_ANY>(a, grid, st);
 }
 
