@@ -96,8 +96,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.sharded:
+        # --sharded on one GPU: a process group of size 1, so that every exchange still goes through RCCL
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from deeprec_amd import kernels as K
@@ -187,9 +189,14 @@ def main():
         Pt.init_normal_(K, 1, 0.01)
         Qt.init_normal_(K, 2, 0.01)
 
+        # samples go to the owner of their user row, distinct item rows come in, item gradient rows go out; the
+        # id-only routing of batch t+1 runs on a second stream / communicator while batch t's kernels execute
+        trainer = sh.ShardedBpr(K, Pt, Qt)
+        trainer.prefetch(*batches[0])
+        launch = "eager; routes (id exchanges, owners' segment plans) one batch ahead on a second stream"
+
         def step(t):
-            u, i, j = batches[t % len(batches)]
-            return sh.sharded_bpr_step(K, Pt, Qt, u, i, j, opt_for(t + 1))
+            return trainer.step(opt_for(t + 1), next_batch=batches[(t + 1) % len(batches)])
 
     def barrier():
         if world > 1:
@@ -232,7 +239,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

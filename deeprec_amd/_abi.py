@@ -63,6 +63,11 @@ SIGNATURES = {
     "dr_sample_negatives_i32": (_i32, [_p, _p, _p, _i64, _i32, _i64, _i64, _i64, C.c_uint64, C.c_uint64, _p, _p]),
     "dr_bucket_order_bytes": (_i64, [_i64]),
     "dr_bucket_order_i32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "dr_route_bytes": (_i64, [_i64]),
+    "dr_route_samples_i32": (_i32, [_p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "dr_route_items_i32": (_i32, [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "dr_canon_contributions_i32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "dr_bpr_item_grads_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _p]),
     "dr_profile_enable": (_i32, [_i32]),
     "dr_profile_collect": (_i32, [C.c_char_p, _i64, C.POINTER(C.c_float), _i32]),
 }

@@ -172,6 +172,78 @@ def bucket_order(keys, nkeys):
     return order, counts
 
 
+def _route_ws(n_keys, device):
+    need = check(_abi.lib().dr_route_bytes(int(n_keys)), "dr_route_bytes")
+    return torch.empty(max(need, 256), dtype=torch.uint8, device=device)
+
+
+def route_samples(u, i, j, world, num_user, num_item, tag):
+    """Samples of one batch -> the rank that owns their user row (deeprec_amd/sharding.py).  Returns
+    (tuples int32 [B,4] = (u // world, i, j, tag + position), bucketed by u % world in batch order;
+    counts int64 [world+1], the last entry counting samples with an id out of range).  No host sync."""
+    B = _i32(u, "u").numel()
+    if _i32(i, "i").numel() != B or _i32(j, "j").numel() != B:
+        raise ValueError("u, i, j must have the same length")
+    tup = torch.empty((B, 4), dtype=torch.int32, device=u.device)
+    counts = torch.empty(world + 1, dtype=torch.int64, device=u.device)
+    ws = _route_ws(B, u.device)
+    check(_abi.lib().dr_route_samples_i32(_ptr(u), _ptr(i), _ptr(j), B, int(world), int(num_user), int(num_item),
+                                          int(tag), _ptr(tup), _ptr(counts), _ptr(ws), ws.numel(), _stream()),
+          "dr_route_samples_i32")
+    return tup, counts
+
+
+class ItemRoute:
+    __slots__ = ("u_loc", "inv", "uniq_rows", "meta", "order", "counts")
+
+
+def route_items(samples, world, rows_per_owner, part_bit):
+    """Received sample tuples [n,4] -> distinct item rows to fetch per owner, the index of every (sample, i|j) entry
+    in that list, and the wire order / metadata of the item-side gradient contributions (include/deeprec_amd.h)."""
+    samples = _req(samples, torch.int32, "samples", 2)
+    n = samples.shape[0]
+    if samples.shape[1] != 4:
+        raise ValueError("samples must be [n,4]")
+    dev = samples.device
+    r = ItemRoute()
+    r.u_loc = torch.empty(n, dtype=torch.int32, device=dev)
+    r.inv = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    r.uniq_rows = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    r.meta = torch.empty((2 * n, 2), dtype=torch.int32, device=dev)
+    r.order = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    r.counts = torch.empty((world, 2), dtype=torch.int64, device=dev)
+    ws = _route_ws(2 * n, dev)
+    check(_abi.lib().dr_route_items_i32(_ptr(samples), n, int(world), int(rows_per_owner), int(part_bit), _ptr(r.u_loc),
+                                        _ptr(r.inv), _ptr(r.uniq_rows), _ptr(r.meta), _ptr(r.order), _ptr(r.counts),
+                                        _ptr(ws), ws.numel(), _stream()), "dr_route_items_i32")
+    return r
+
+
+def canon_contributions(meta, key_bits):
+    """Received (row, global key) pairs [n,2] -> (ids_canon int32 [n], perm int32 [n]): ascending global key."""
+    meta = _req(meta, torch.int32, "meta", 2)
+    n = meta.shape[0]
+    ids = torch.empty(n, dtype=torch.int32, device=meta.device)
+    perm = torch.empty(n, dtype=torch.int32, device=meta.device)
+    ws = _route_ws(n, meta.device)
+    check(_abi.lib().dr_canon_contributions_i32(_ptr(meta), n, int(key_bits), _ptr(ids), _ptr(perm), _ptr(ws),
+                                                ws.numel(), _stream()), "dr_canon_contributions_i32")
+    return ids, perm
+
+
+def bpr_item_grads(P, u_loc, g, order):
+    """Item-side gradient rows of a BPR batch in wire order: out[y] = (+-g[s]) * P[u_loc[s]], e = order[y], s = e mod n,
+    minus for e >= n (bprmf.py:118-121: d loss / d q_i = g * p_u, d loss / d q_j = -g * p_u)."""
+    P = _req(P, torch.float32, "P", 2)
+    n = _i32(u_loc, "u_loc").numel()
+    if _req(g, torch.float32, "g", 1).numel() != n or _i32(order, "order").numel() != 2 * n:
+        raise ValueError("g must be [n], order [2n]")
+    out = torch.empty((2 * n, P.shape[1]), dtype=torch.float32, device=P.device)
+    check(_abi.lib().dr_bpr_item_grads_f32(_ptr(P), P.shape[0], P.shape[1], _ptr(u_loc), _ptr(g), _ptr(order), n,
+                                           _ptr(out), _stream()), "dr_bpr_item_grads_f32")
+    return out
+
+
 def scatter_add(gtable, ids, src, src_idx=None, coef=None, plan=None):
     """gtable[ids[e]] += coef[e] * src[src_idx[e]] in place, duplicates summed deterministically."""
     gtable = _req(gtable, torch.float32, "gtable")

@@ -3,18 +3,25 @@ counterpart -- the reference is single-process, single-device).
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  A table of R rows is
 dealt round-robin: global row r lives on rank r % W at local row r // W (balances popular items
-better than contiguous blocks).  A training step exchanges, per table,
+better than contiguous blocks).
 
-    ids   -> owners        all-to-all-v   (4 B per lookup)
-    rows  <- owners        all-to-all-v   (4k B per lookup, owners run the gather kernel)
-    grads -> owners        all-to-all-v   (4k B per lookup)
+A BPR step moves the *sample* to the data where that is cheaper than moving the data to the sample:
 
-(the u list in one exchange, the i and j lists together in a second one: StepRoutes)
+    samples (u, i, j, position)  -> the owner of P[u]      16 B per sample   (user rows never travel)
+    distinct item rows           <- the owners of Q rows   4k B per DISTINCT item a rank's samples touch
+    item gradient rows           -> the owners of Q rows   4k B per (sample, item) contribution
 
-and the owners run the deterministic sorted-segment row update on what they received.  The received
-contributions are laid out in ascending *global batch position* (rank-major, then batch order; for Q
-all positive-item contributions precede all negative-item ones), i.e. exactly the order a single
-process sees for the concatenated global batch, so tables are bit-identical at every world size.
+The processing rank (owner of the user row) runs the lookup / dot / loss kernel on its own P shard
+and the fetched Q rows, updates its P rows locally, and ships one gradient row per item occurrence.
+Duplicate item gradients are NOT pre-summed on the sender: every contribution carries its global key
+(i-part before j-part, then source rank, then batch position) and the owner sums them in ascending
+key order, i.e. exactly the order a single process sees for the concatenated global batch, so the
+tables are bit-identical at every world size.
+
+Everything that depends on the ids only (bucketing, id exchanges, the owners' segment plans: `route`)
+is separated from what depends on table values (`run`), so a trainer routes batch t+1 on a second
+stream / second communicator while batch t runs (`ShardedBpr.step(..., next_batch=...)`); the two
+host synchronisations of a route (variable all-to-all split sizes) then wait on short id kernels only.
 
 `ops` is the kernel namespace (default: deeprec_amd.kernels = the HIP library).  The package ships no
 other implementation; tests inject an oracle-backed namespace to exercise the exchange logic on CPU
@@ -23,61 +30,16 @@ with gloo.
 import torch
 import torch.distributed as dist
 
+POS_BITS = 24                    # batch position inside the source rank's batch
+RANK_BITS = 6                    # source rank (ranks of one node)
+PART_BIT = POS_BITS + RANK_BITS  # 0: positive item i, 1: negative item j  -> global keys have 31 bits
+
 
 def _a2a(out, inp, out_splits, in_splits, group):
+    """The one collective of this module (module-level so that a test can stage device tensors through the host
+    when it runs several ranks on one GPU under gloo)."""
     dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
     return out
-
-
-class Exchange:
-    """Routing of one id list to the owning ranks and back."""
-
-    def __init__(self, ids, world, rank, group=None):
-        self.world, self.rank, self.group = world, rank, group
-        ids = ids.reshape(-1)
-        self.n = ids.numel()
-        owner = (ids % world).to(torch.int64)
-        # stable bucket by owner keeps batch order inside each destination
-        self.order = torch.sort(owner, stable=True)[1]
-        send_counts = torch.bincount(owner, minlength=world)
-        recv_counts = torch.empty_like(send_counts)
-        if world > 1:
-            dist.all_to_all_single(recv_counts, send_counts, group=group)
-        else:
-            recv_counts.copy_(send_counts)
-        self.send_splits = send_counts.tolist()          # host sync: sizes of the variable all-to-all
-        self.recv_splits = recv_counts.tolist()
-        self.n_recv = int(sum(self.recv_splits))
-        local_rows = torch.div(ids, world, rounding_mode="floor").to(torch.int32)
-        send_rows = local_rows[self.order].contiguous()
-        self.owner_rows = torch.empty(self.n_recv, dtype=torch.int32, device=ids.device)
-        if world > 1:
-            _a2a(self.owner_rows, send_rows, self.recv_splits, self.send_splits, group)
-        else:
-            self.owner_rows.copy_(send_rows)
-        self.inv = torch.empty_like(self.order)
-        self.inv[self.order] = torch.arange(self.n, device=ids.device)
-
-    def fetch(self, rows_at_owner):
-        """Owner-side rows [n_recv, k] -> requester-side rows [n, k] in original id order."""
-        k = rows_at_owner.shape[1]
-        back = torch.empty((self.n, k), dtype=rows_at_owner.dtype, device=rows_at_owner.device)
-        if self.world > 1:
-            _a2a(back, rows_at_owner.contiguous(), self.send_splits, self.recv_splits, self.group)
-        else:
-            back.copy_(rows_at_owner)
-        return back[self.inv].contiguous()
-
-    def push(self, rows):
-        """Requester-side rows [n, k] (original id order) -> owner-side rows [n_recv, k], rank-major."""
-        k = rows.shape[1]
-        out = torch.empty((self.n_recv, k), dtype=rows.dtype, device=rows.device)
-        send = rows[self.order].contiguous()
-        if self.world > 1:
-            _a2a(out, send, self.recv_splits, self.send_splits, self.group)
-        else:
-            out.copy_(send)
-        return out
 
 
 class ShardedTable:
@@ -110,130 +72,169 @@ class ShardedTable:
             self.w[l0:l0 + part.shape[0]].copy_(part)
 
 
-_HELPER = {}
+_SIDE = {}
 
 
-def _helper_stream(device):
+def _side_stream(device):
     key = (device.type, device.index)
-    if key not in _HELPER:
-        _HELPER[key] = torch.cuda.Stream(device=device)
-    return _HELPER[key]
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
-class StepRoutes:
-    """Routing of one BPR batch: u -> owners of P rows, (i, j) -> owners of Q rows.
+class BprRoute:
+    """Everything about one step that depends on the ids only (see ShardedBpr.route)."""
+    __slots__ = ("n_s", "n_uq", "n_f", "n_g", "send_f", "recv_f", "send_g", "recv_g", "u_loc", "inv_i", "inv_j",
+                 "order_g", "rows_fetch", "ids_canon", "perm", "plan_p", "plan_q", "ready", "keep")
 
-    One count exchange and ONE host synchronisation serve both tables.  Wire order towards owner r is, per
-    table, the requester's batch order (stable bucket by owner); for Q each requester sends [its i's | its j's].
-    The owner-side canonical contribution order -- all positive items of the global batch (rank-major, batch
-    order), then all negative items -- is the index list `q_perm` into what was received, so no payload is
-    ever re-ordered in memory: kernels take it as `src_idx`."""
 
-    def __init__(self, ops, u, i, j, world, rank, group=None):
-        self.world, self.rank, self.group = world, rank, group
-        dev = u.device
-        B = u.numel()
-        self.B = B
-        W = world
-        ij = torch.cat((i, j))
-        oq = (ij % W) * 2
-        oq[B:] += 1                                              # key = owner * 2 + part (0: i, 1: j)
-        self.order_u, cu = ops.bucket_order((u % W).to(torch.int32), W)
-        self.order_q, cq = ops.bucket_order(oq.to(torch.int32), 2 * W)
-        self.order_u, self.order_q = self.order_u.long(), self.order_q.long()
-        counts = torch.cat((cu[:, None], cq.view(W, 2)), 1)
-        recv = torch.empty_like(counts)
-        if W > 1:
-            dist.all_to_all_single(recv, counts, group=group)    # row s of recv = what rank s sends here
-        else:
-            recv.copy_(counts)
-        both = torch.stack((counts, recv)).tolist()              # the step's one host sync (variable split sizes)
-        sc, rc = both
-        self.send_u = [c[0] for c in sc]
-        self.recv_u = [c[0] for c in rc]
-        self.send_q = [c[1] + c[2] for c in sc]
-        self.recv_q = [c[1] + c[2] for c in rc]
-        self.n_recv_u, self.n_recv_q = sum(self.recv_u), sum(self.recv_q)
-        # local row ids at the owners
-        self.rows_u = self._a2a(torch.div(u, W, rounding_mode="floor").to(torch.int32)[self.order_u].contiguous(),
-                                self.n_recv_u, self.recv_u, self.send_u)
-        self.rows_q = self._a2a(torch.div(ij, W, rounding_mode="floor").to(torch.int32)[self.order_q].contiguous(),
-                                self.n_recv_q, self.recv_q, self.send_q)
-        # canonical owner-side order of the Q contributions: every source's i-part, then every source's j-part
-        off, ip, jp = 0, [], []
-        for s in range(W):
-            ci, cj = rc[s][1], rc[s][2]
-            ip.append((off, off + ci))
-            jp.append((off + ci, off + ci + cj))
-            off += ci + cj
-        self.q_perm = torch.cat([torch.arange(lo, hi, dtype=torch.int32, device=dev) for lo, hi in ip + jp]) \
-            if off else torch.zeros(0, dtype=torch.int32, device=dev)
-        # where each sample's rows sit in the fetched (owner-sorted) buffers
-        ar = torch.arange(B, dtype=torch.int32, device=dev)
-        self.inv_u = torch.empty(B, dtype=torch.int32, device=dev)
-        self.inv_u[self.order_u] = ar
-        self.inv_q = torch.empty(2 * B, dtype=torch.int32, device=dev)
-        self.inv_q[self.order_q] = torch.arange(2 * B, dtype=torch.int32, device=dev)
+class ShardedBpr:
+    """BPR-MF training steps (bprmf.py:114-123) over row-sharded P and Q.
 
-    def _a2a(self, send, n_out, out_splits, in_splits):
+    route(u, i, j) -> BprRoute      ids only: 5 collectives, 2 host syncs, the owners' segment plans
+    run(route, opt) -> loss         table values: 2 collectives (rows in, gradient rows out), no host sync
+    step(opt, next_batch)           run the prefetched route, then route next_batch on the side stream
+
+    group: communicator of the row / gradient exchanges; route_group: communicator of the id exchanges (created
+    here when the step is pipelined on GPUs, because the two run concurrently on different streams)."""
+
+    def __init__(self, ops, P, Q, group=None, route_group=None, pipelined=None):
+        if P.world != Q.world or P.rank != Q.rank or P.k != Q.k:
+            raise ValueError("P and Q must be sharded over the same ranks and share k")
+        self.ops, self.P, self.Q = ops, P, Q
+        self.world, self.rank, self.group = P.world, P.rank, group
+        if self.world > (1 << RANK_BITS):
+            raise ValueError("at most %d ranks" % (1 << RANK_BITS))
+        self.cuda = P.w.is_cuda
+        self.pipelined = self.cuda if pipelined is None else bool(pipelined)
+        self.collective = self.world > 1 or (dist.is_available() and dist.is_initialized())
+        if route_group is None and self.pipelined and self.cuda and self.collective:
+            route_group = dist.new_group()          # collective call: every rank constructs its trainer
+        self.route_group = route_group if route_group is not None else group
+        self.rpo = (Q.rows + self.world - 1) // self.world     # local rows per owner (upper bound)
+        self.side = _side_stream(P.w.device) if (self.cuda and self.pipelined) else None
+        self._pending = None
+        self._ev_done = None        # end of the previous run() on the main stream
+
+    # ---- exchanges -------------------------------------------------------------------------------------
+    def _x(self, send, n_out, out_splits, in_splits, group):
+        if not self.collective:
+            return send                                            # one rank, no process group: nothing travels
         out = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        if self.world > 1:
-            dist.all_to_all_single(out, send, out_splits, in_splits, group=self.group)
+        return _a2a(out, send, out_splits, in_splits, group)
+
+    def _counts(self, counts, group):
+        """Exchange per-destination counts; returns (sent, received) as host lists: one host synchronisation."""
+        recv = self._x(counts, counts.shape[0], None, None, group)
+        sent, got = torch.stack((counts, recv)).tolist()
+        return sent, got
+
+    # ---- ids only --------------------------------------------------------------------------------------
+    def route(self, u, i, j):
+        ops, W, g = self.ops, self.world, self.route_group
+        P, Q = self.P, self.Q
+        B = u.numel()
+        if B >= (1 << POS_BITS):
+            raise ValueError("batch of %d samples per rank exceeds 2^%d" % (B, POS_BITS))
+        rt = BprRoute()
+        # samples -> owners of their user rows
+        tup, cnt = ops.route_samples(u, i, j, W, P.rows, Q.rows, self.rank << POS_BITS)
+        sc, rc = self._counts(cnt[:W], g)                          # host sync 1 (cnt[W]: invalid ids, checked below)
+        rt.n_s = n_s = int(sum(rc))
+        n_valid = int(sum(sc))
+        if n_valid != B:
+            raise IndexError("sharded BPR step: %d of %d samples have a user / item id out of range" % (B - n_valid, B))
+        smp = self._x(tup[:n_valid], n_s, rc, sc, g)               # [n_s, 4] in (source rank, batch position) order
+        # item rows to fetch (distinct, per owner) and the contribution lists
+        ri = ops.route_items(smp, W, self.rpo, PART_BIT)
+        s2, r2 = self._counts(ri.counts, g)                        # host sync 2
+        rt.send_f, rt.recv_f = [c[0] for c in s2], [c[0] for c in r2]
+        rt.send_g, rt.recv_g = [c[1] for c in s2], [c[1] for c in r2]
+        rt.n_uq, rt.n_f, rt.n_g = int(sum(rt.send_f)), int(sum(rt.recv_f)), int(sum(rt.recv_g))
+        rt.rows_fetch = self._x(ri.uniq_rows[:rt.n_uq], rt.n_f, rt.recv_f, rt.send_f, g)
+        meta_r = self._x(ri.meta, rt.n_g, rt.recv_g, rt.send_g, g)
+        rt.ids_canon, rt.perm = ops.canon_contributions(meta_r, PART_BIT + 1)
+        rt.u_loc, rt.order_g = ri.u_loc, ri.order
+        rt.inv_i, rt.inv_j = ri.inv[:n_s], ri.inv[n_s:]
+        # the owners' segment plans (namespaces without SegmentPlan -- the CPU oracle in tests -- plan in the update)
+        rt.plan_p = rt.plan_q = None
+        if hasattr(ops, "SegmentPlan"):
+            if n_s:
+                rt.plan_p = ops.SegmentPlan(rt.u_loc, P.w.shape[0], k_max=P.k)
+            if rt.n_g:
+                rt.plan_q = ops.SegmentPlan(rt.ids_canon, Q.w.shape[0], k_max=Q.k)
+        rt.ready = None
+        rt.keep = (tup, smp, ri, meta_r)        # wire buffers: alive until the step that uses the route is enqueued
+        return rt
+
+    # ---- table values ----------------------------------------------------------------------------------
+    def run(self, rt, opt):
+        ops, P, Q, g = self.ops, self.P, self.Q, self.group
+        dev = P.w.device
+        # distinct item rows <- owners (the owners run K1 on their shard)
+        served = ops.gather(Q.w, rt.rows_fetch) if rt.n_f else torch.empty((0, Q.k), dtype=torch.float32, device=dev)
+        qc = self._x(served, rt.n_uq, rt.send_f, rt.recv_f, g)
+        if rt.n_s:
+            # lookup + dots + loss on the local P shard and the fetched rows; stash = g * (q_i - q_j)
+            gc, loss_b, stash = ops.bpr_forward(P.w, qc, rt.u_loc, rt.inv_i, rt.inv_j)
+            q_send = ops.bpr_item_grads(P.w, rt.u_loc, gc, rt.order_g)         # reads pre-step P rows
         else:
-            out.copy_(send)
-        return out
+            q_send = torch.empty((0, Q.k), dtype=torch.float32, device=dev)
+        q_grad = self._x(q_send, rt.n_g, rt.recv_g, rt.send_g, g)
+        # deterministic segment updates; contributions in ascending global batch position
+        if rt.n_s:
+            ops.sparse_row_update(P.w, P.slot(0), P.slot(1), rt.u_loc, stash, opt, plan=rt.plan_p)
+        if rt.n_g:
+            ops.sparse_row_update(Q.w, Q.slot(0), Q.slot(1), rt.ids_canon, q_grad, opt, src_idx=rt.perm, plan=rt.plan_q)
+        if rt.n_s:
+            return ops.sum_f32(loss_b)
+        return torch.zeros(1, dtype=torch.float32, device=dev)
 
-    def fetch_u(self, rows_at_owner):   # [n_recv_u, k] -> [B, k], requester's owner-sorted order
-        return self._a2a(rows_at_owner, self.B, self.send_u, self.recv_u)
+    # ---- one batch ahead -------------------------------------------------------------------------------
+    def prefetch(self, u, i, j):
+        """Route a batch now (on the side stream when pipelined); step() consumes it."""
+        if self.side is None:
+            self._pending = self.route(u, i, j)
+            return
+        if self._ev_done is not None:
+            self.side.wait_event(self._ev_done)     # memory of routes retired before that point may be reused
+        else:
+            self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            rt = self.route(u, i, j)
+            rt.ready = torch.cuda.Event()
+            rt.ready.record(self.side)
+        self._pending = rt
 
-    def fetch_q(self, rows_at_owner):   # [n_recv_q, k] -> [2B, k]
-        return self._a2a(rows_at_owner, 2 * self.B, self.send_q, self.recv_q)
-
-    def push_u(self, rows_sorted):      # [B, k] in owner-sorted order -> [n_recv_u, k], rank-major
-        return self._a2a(rows_sorted, self.n_recv_u, self.recv_u, self.send_u)
-
-    def push_q(self, rows_sorted):      # [2B, k] -> [n_recv_q, k], wire order (see q_perm)
-        return self._a2a(rows_sorted, self.n_recv_q, self.recv_q, self.send_q)
+    def step(self, opt, next_batch=None):
+        """Run the prefetched batch; then route `next_batch` = (u, i, j) while those kernels execute."""
+        rt = self._pending
+        if rt is None:
+            raise RuntimeError("ShardedBpr.step: no routed batch (call prefetch first)")
+        self._pending = None
+        if rt.ready is not None:
+            torch.cuda.current_stream().wait_event(rt.ready)
+        loss = self.run(rt, opt)
+        if self.side is not None:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream())
+            # prefetch() lets the side stream wait for the end of the PREVIOUS step only (so the route overlaps this
+            # step's kernels): side-stream memory it may reuse belongs to routes retired before that point, and this
+            # step's route (rt) stays referenced until the next one has been built
+            if next_batch is not None:
+                self.prefetch(*next_batch)
+            self._ev_done = done
+        elif next_batch is not None:
+            self.prefetch(*next_batch)
+        return loss
 
 
 def sharded_bpr_step(ops, P, Q, u, i, j, opt, group=None):
-    """One BPR-MF step (bprmf.py:114-123) over row-sharded P, Q for this rank's batch (u, i, j) of
-    GLOBAL ids (int32 [B]).  Returns this rank's loss sum (device scalar tensor).
-
-    7 collectives (1 count, 2 id, 2 row, 2 gradient all-to-alls) and one host synchronisation per step; no
-    payload row is copied except by the kernels that produce or consume it (lookups and gradient rows are
-    addressed through index lists)."""
-    world, rank = P.world, P.rank
-    B = u.numel()
-    rt = StepRoutes(ops, u, i, j, world, rank, group)
-    q_ids = rt.rows_q[rt.q_perm.long()].contiguous()
-    # The owners' segment plans depend on the routed ids only: build them on a helper stream while the rows and
-    # gradients travel.  (Namespaces without SegmentPlan -- the CPU oracle in tests -- plan inside the update.)
-    plan_q = plan_p = side = None
-    if world > 1 and hasattr(ops, "SegmentPlan") and u.is_cuda:   # one rank: nothing travels, nothing to hide behind
-        main = torch.cuda.current_stream()
-        side = _helper_stream(u.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            plan_q = ops.SegmentPlan(q_ids, Q.w.shape[0], k_max=Q.k)
-            plan_p = ops.SegmentPlan(rt.rows_u, P.w.shape[0], k_max=P.k)
-    # rows <- owners (the owners run K1 on their shard); they arrive in owner-sorted order and stay there
-    pu = rt.fetch_u(ops.gather(P.w, rt.rows_u))
-    qc = rt.fetch_q(ops.gather(Q.w, rt.rows_q))
-    # local interaction + loss: sample b reads pu[inv_u[b]], qc[inv_q[b]], qc[inv_q[B + b]]
-    g, loss_b, stash = ops.bpr_forward(pu, qc, rt.inv_u, rt.inv_q[:B].contiguous(), rt.inv_q[B:].contiguous())
-    # grads -> owners, produced directly in wire order.  Q: +g * p_u for the i-entry, -g * p_u for the j-entry
-    # of each sample (pu is a private pre-step copy, so the Q-before-P ordering of the fused step is moot here)
-    coef = torch.cat((g, -g))[rt.order_q].contiguous()
-    src_row = rt.inv_u[(rt.order_q % B)].contiguous()
-    q_grad = rt.push_q(ops.scale_rows(pu, coef, src_row))
-    p_grad = rt.push_u(ops.gather(stash, rt.order_u.to(torch.int32)))
-    # the owners' deterministic segment updates; contributions in ascending global batch position
-    if side is not None:
-        torch.cuda.current_stream().wait_stream(side)
-    ops.sparse_row_update(Q.w, Q.slot(0), Q.slot(1), q_ids, q_grad, opt, src_idx=rt.q_perm, plan=plan_q)
-    ops.sparse_row_update(P.w, P.slot(0), P.slot(1), rt.rows_u, p_grad, opt, plan=plan_p)
-    return ops.sum_f32(loss_b)
+    """One BPR-MF step (bprmf.py:114-123) over row-sharded P, Q for this rank's batch (u, i, j) of GLOBAL ids
+    (int32 [B]), unpipelined.  Returns the loss sum of the samples this rank PROCESSED (those whose user row it
+    owns; all-reduce it for the global loss) as a device scalar tensor."""
+    tr = ShardedBpr(ops, P, Q, group=group, route_group=group, pipelined=False)
+    return tr.run(tr.route(u, i, j), opt)
 
 
 def shard_users(n_users, world, rank):

@@ -24,6 +24,64 @@ def bucket_order(keys, nkeys):
     return torch.from_numpy(order), torch.from_numpy(np.bincount(kk, minlength=nkeys).astype(np.int64))
 
 
+def route_samples(u, i, j, world, num_user, num_item, tag):
+    """numpy restatement of dr_route_samples_i32 (include/deeprec_amd.h)."""
+    u, i, j = (_n(x).astype(np.int64) for x in (u, i, j))
+    bad = (u < 0) | (u >= num_user) | (i < 0) | (i >= num_item) | (j < 0) | (j >= num_item)
+    key = np.where(bad, world, u % world)
+    order = np.argsort(key, kind="stable")
+    tup = np.stack((u // world, i, j, tag + np.arange(len(u))), 1)[order].astype(np.int32)
+    return torch.from_numpy(tup.reshape(-1, 4)), torch.from_numpy(np.bincount(key, minlength=world + 1).astype(np.int64))
+
+
+class ItemRoute:
+    pass
+
+
+def route_items(samples, world, rows_per_owner, part_bit):
+    """numpy restatement of dr_route_items_i32."""
+    smp = _n(samples).astype(np.int64).reshape(-1, 4)
+    n = smp.shape[0]
+    ids = np.concatenate((smp[:, 1], smp[:, 2]))
+    gkey = np.concatenate((smp[:, 3], smp[:, 3] | (1 << part_bit)))
+    okey = (ids % world) * rows_per_owner + ids // world
+    order = np.argsort(okey, kind="stable")
+    sk = okey[order]
+    head = np.ones(2 * n, dtype=bool)
+    head[1:] = sk[1:] != sk[:-1]
+    seg = np.cumsum(head) - 1
+    inv = np.empty(2 * n, dtype=np.int32)
+    inv[order] = seg
+    uniq = sk[head]
+    r = ItemRoute()
+    r.u_loc = torch.from_numpy(smp[:, 0].astype(np.int32))
+    r.inv = torch.from_numpy(inv)
+    ur = np.zeros(2 * n, dtype=np.int32)
+    ur[:len(uniq)] = uniq % rows_per_owner
+    r.uniq_rows = torch.from_numpy(ur)
+    r.meta = torch.from_numpy(np.stack((sk % rows_per_owner, gkey[order]), 1).astype(np.int32).reshape(-1, 2))
+    r.order = torch.from_numpy(order.astype(np.int32))
+    r.counts = torch.from_numpy(np.stack((np.bincount(uniq // rows_per_owner, minlength=world),
+                                          np.bincount(ids % world, minlength=world)), 1).astype(np.int64))
+    return r
+
+
+def canon_contributions(meta, key_bits):
+    """numpy restatement of dr_canon_contributions_i32."""
+    m = _n(meta).reshape(-1, 2)
+    perm = np.argsort(m[:, 1], kind="stable").astype(np.int32)
+    return torch.from_numpy(m[perm, 0].astype(np.int32)), torch.from_numpy(perm)
+
+
+def bpr_item_grads(P, u_loc, g, order):
+    """numpy restatement of dr_bpr_item_grads_f32."""
+    P, u_loc, g, order = _n(P), _n(u_loc), _n(g), _n(order)
+    n = len(u_loc)
+    s = order % n if n else order
+    coef = np.where(order < n, g[s], -g[s]).astype(np.float32)
+    return torch.from_numpy((coef[:, None] * P[u_loc[s]]).astype(np.float32).reshape(2 * n, P.shape[1]))
+
+
 def bpr_forward(P, Q, u, i, j):
     lb, g, _ = ro.bpr_forward(_n(P), _n(Q), _n(u), _n(i), _n(j))
     stash = (g[:, None] * (ro.gather(_n(Q), _n(i)) - ro.gather(_n(Q), _n(j)))).astype(np.float32)

@@ -26,7 +26,7 @@ def _case(seed, nu, ni, k, Bg):
     P = (rng.standard_normal((nu, k)) * 0.1).astype(np.float32)
     Q = (rng.standard_normal((ni, k)) * 0.1).astype(np.float32)
     steps = []
-    for _ in range(2):
+    for _ in range(3):
         u = rng.integers(0, nu, Bg).astype(np.int32)
         i = (rng.zipf(1.3, Bg) % ni).astype(np.int32)       # duplicate-heavy
         j = rng.integers(0, ni, Bg).astype(np.int32)
@@ -34,7 +34,7 @@ def _case(seed, nu, ni, k, Bg):
     return P, Q, steps
 
 
-def _worker(rank, world, port, seed, kind, out):
+def _worker(rank, world, port, seed, kind, out, api):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -52,12 +52,18 @@ def _worker(rank, world, port, seed, kind, out):
         Qt.load_global(torch.from_numpy(Q))
         Bl = Bg // world
         losses = []
-        for t, (u, i, j) in enumerate(steps, 1):
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        mine = [tuple(torch.from_numpy(x[sl]) for x in b) for b in steps]
+        tr = sh.ShardedBpr(ops, Pt, Qt)
+        if api == "trainer":
+            tr.prefetch(*mine[0])
+        for t in range(1, len(mine) + 1):
             opt = K.opt_params(kind, lr=0.05, alpha=float(ro.adam_alpha(1e-3, 0.9, 0.999, t)), eps=1e-7, reg=0.01,
                                reg_mode=K.REG_TOUCHED)
-            sl = slice(rank * Bl, (rank + 1) * Bl)
-            l = sh.sharded_bpr_step(ops, Pt, Qt, torch.from_numpy(u[sl]), torch.from_numpy(i[sl]),
-                                    torch.from_numpy(j[sl]), opt)
+            if api == "trainer":        # the prefetch / step protocol bench.py uses
+                l = tr.step(opt, next_batch=mine[t] if t < len(mine) else None)
+            else:
+                l = sh.sharded_bpr_step(ops, Pt, Qt, *mine[t - 1], opt)
             dist.all_reduce(l)
             losses.append(float(l))
         Pfull = sh.all_gather_table(Pt).numpy()
@@ -68,12 +74,12 @@ def _worker(rank, world, port, seed, kind, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,api", [(2, "wrapper"), (2, "trainer"), (3, "trainer")])
 @pytest.mark.parametrize("kind", [ro.OPT_SGD, ro.OPT_ADAM])
-def test_sharded_step_equals_single_process(tmp_path, world, kind):
+def test_sharded_step_equals_single_process(tmp_path, world, kind, api):
     seed = 5
     out = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(world, _free_port(), seed, kind, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), seed, kind, out, api), nprocs=world, join=True)
     res = np.load(out)
     P, Q, steps = _case(seed, 101, 57, 8, 96)
     sP = [np.zeros_like(P), np.zeros_like(P)] if kind == ro.OPT_ADAM else []
