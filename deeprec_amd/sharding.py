@@ -35,11 +35,10 @@ RANK_BITS = 6                    # source rank (ranks of one node)
 PART_BIT = POS_BITS + RANK_BITS  # 0: positive item i, 1: negative item j  -> global keys have 31 bits
 
 
-def _a2a(out, inp, out_splits, in_splits, group):
+def _a2a(out, inp, out_splits, in_splits, group, async_op=False):
     """The one collective of this module (module-level so that a test can stage device tensors through the host
-    when it runs several ranks on one GPU under gloo)."""
-    dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
-    return out
+    when it runs several ranks on one GPU under gloo).  Returns the work handle when async_op, else None."""
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
 
 
 class ShardedTable:
@@ -117,11 +116,13 @@ class ShardedBpr:
         self._ev_done = None        # end of the previous run() on the main stream
 
     # ---- exchanges -------------------------------------------------------------------------------------
-    def _x(self, send, n_out, out_splits, in_splits, group):
+    def _x(self, send, n_out, out_splits, in_splits, group, async_op=False):
+        """All-to-all-v along dim 0.  async_op: returns (out, work); the caller waits before it reads `out`."""
         if not self.collective:
-            return send                                            # one rank, no process group: nothing travels
+            return (send, None) if async_op else send              # one rank, no process group: nothing travels
         out = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        return _a2a(out, send, out_splits, in_splits, group)
+        work = _a2a(out, send, out_splits, in_splits, group, async_op)
+        return (out, work) if async_op else out
 
     def _counts(self, counts, group):
         """Exchange per-destination counts; returns (sent, received) as host lists: one host synchronisation."""
@@ -180,10 +181,13 @@ class ShardedBpr:
             q_send = ops.bpr_item_grads(P.w, rt.u_loc, gc, rt.order_g)         # reads pre-step P rows
         else:
             q_send = torch.empty((0, Q.k), dtype=torch.float32, device=dev)
-        q_grad = self._x(q_send, rt.n_g, rt.recv_g, rt.send_g, g)
-        # deterministic segment updates; contributions in ascending global batch position
+        q_grad, travelling = self._x(q_send, rt.n_g, rt.recv_g, rt.send_g, g, async_op=True)
+        # deterministic segment updates; contributions in ascending global batch position.  The user side is local
+        # and runs while the item gradients travel (q_send was computed from the pre-step P rows above).
         if rt.n_s:
             ops.sparse_row_update(P.w, P.slot(0), P.slot(1), rt.u_loc, stash, opt, plan=rt.plan_p)
+        if travelling is not None:
+            travelling.wait()
         if rt.n_g:
             ops.sparse_row_update(Q.w, Q.slot(0), Q.slot(1), rt.ids_canon, q_grad, opt, src_idx=rt.perm, plan=rt.plan_q)
         if rt.n_s:

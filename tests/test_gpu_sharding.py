@@ -191,11 +191,15 @@ def _worker2(rank, world, port, out):
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
 
-        def staged(o, inp, out_splits, in_splits, group):     # gloo has no device all-to-all: stage through the host
-            oc = torch.empty(o.shape, dtype=o.dtype)
+        def staged(o, inp, out_splits, in_splits, group, async_op=False):
+            oc = torch.empty(o.shape, dtype=o.dtype)          # gloo has no device all-to-all: stage through the host
             dist.all_to_all_single(oc, inp.cpu(), out_splits, in_splits, group=group)
             o.copy_(oc)
-            return o
+
+            class Done:
+                def wait(self):
+                    return True
+            return Done() if async_op else None
 
         sh._a2a = staged
         P0, Q0, batches = _case(33, 5001, 801, 64, 4096, 4)
