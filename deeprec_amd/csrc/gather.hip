@@ -76,8 +76,8 @@ static int launch_gather(const float* table, int64_t rows, int k, const IdT* ids
     constexpr int U = 4;
     constexpr int RPB = (64 / LPR) * 4;
     int grid = grid_for(n, 1, RPB * U);
-    DR_LAUNCH((gather_kernel<V, LPR, U, IdT>), dim3(grid), dim3(256), 0, st, table, rows, k, ids, n,
-                       out, oob_count);
+    DR_LAUNCH_NAMED("gather_kernel", (gather_kernel<V, LPR, U, IdT>), dim3(grid), dim3(256), 0, st, table, rows, k, ids,
+                    n, out, oob_count);
     return 0;
 }
 

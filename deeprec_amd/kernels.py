@@ -83,7 +83,7 @@ def gather(table, ids, oob="zero"):
         raise ValueError("table must be [rows] or [rows, k]")
     n = ids.numel()
     out = torch.empty(tuple(ids.shape) + (() if vec else (k,)), dtype=torch.float32, device=table.device)
-    cnt = torch.zeros(1, dtype=torch.int32, device=table.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=table.device) if oob == "error" else None
     check(_abi.lib().dr_gather_f32(_ptr(table), table.shape[0], k, _ptr(ids), n, bits, _ptr(out),
                                    OOB_ERROR if oob == "error" else OOB_ZERO, _ptr(cnt), _stream()), "dr_gather_f32")
     if oob == "error":

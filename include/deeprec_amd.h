@@ -315,7 +315,7 @@ int32_t dr_bpr_item_grads_f32(const float* P, int64_t rows, int32_t k, const int
                               const int32_t* order, int64_t n, float* out, void* stream);
 
 /* ---- measurement hooks (no counterpart in the reference) ---------------------------------------------
- * dr_profile_enable(1): from now on every instrumented kernel launch of this library (the fused step's forward
+ * dr_profile_enable(1): from now on every instrumented kernel launch of this library (the gather kernel, the fused step's forward
  * kernel, the short / long segment update kernels) carries a start / stop HIP event pair that the runtime stamps
  * with the dispatch's own begin and end (hipExtLaunchKernelGGL), on the stream it is launched on;
  * dr_profile_enable(0) stops it.  Do not enable while a stream is being captured into a graph.  Not
