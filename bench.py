@@ -233,6 +233,10 @@ def main():
         "last_loss_sum": last_loss,
     }
 
+    if (world > 1 or args.sharded) and not args.no_extras:
+        ev = sharded_eval(args, K, sh, Pt, Qt, world, rank, device, barrier)
+        if rank == 0:
+            result["eval"] = ev
     if rank == 0 and world == 1 and not args.no_extras and not args.sharded:
         result.update(extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step, eager_step))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -242,6 +246,44 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_eval(args, K, sh, Pt, Qt, world, rank, device, barrier):
+    """Top-10 evaluation with the users sharded data-parallel: every rank scores --eval-users of its own
+    users against the whole catalog (item table replicated by one all-gather, user rows fetched from their owners)."""
+    import torch.distributed as dist
+    Nu, iters = args.eval_users, 3
+    gen = torch.Generator(device=device)
+    gen.manual_seed(7 + rank)
+    users = torch.randint(0, args.users, (Nu,), device=device, generator=gen).to(torch.int32)
+    tr = torch.sort(torch.randint(0, args.items, (Nu, 100), device=device, generator=gen), 1)[0].to(torch.int32)
+    tp = (torch.arange(Nu + 1, device=device) * 100).to(torch.int32)
+    tg = torch.randint(0, args.items, (Nu,), device=device, generator=gen).to(torch.int32)
+    gp = torch.arange(Nu + 1, device=device).to(torch.int32)
+    barrier()
+    t0 = time.perf_counter()
+    Qf = sh.all_gather_table(Qt)
+    barrier()
+    t_rep = time.perf_counter() - t0
+    run = lambda: sh.sharded_eval_topk(K, Pt, Qt, users, 10, train=(tp, tr.reshape(-1).contiguous()), targets=(gp, tg), Q_full=Qf)
+    run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        idx, val, rk, _ = run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    n, hr, ndcg, mrr = sh.reduce_rank_metrics(rk, 10)
+    flops = 2.0 * world * Nu * iters * args.items * args.k
+    return {"users_per_rank": Nu, "items": args.items, "K": 10, "ms_per_pass": dt / iters * 1e3,
+            "users_per_s": world * Nu * iters / dt, "TFLOPs": flops / dt / 1e12,
+            "frac_mfma_f32_peak": flops / dt / 1e12 / (MFMA_F32_PEAK_TFLOPS * world),
+            "item_table_all_gather_ms": t_rep * 1e3, "users_ranked": n, "hr@10": hr, "ndcg@10": ndcg, "mrr": mrr,
+            "parallelism": "users sharded x%d, item table replicated, user rows fetched from their owners" % world}
 
 
 ROCPROF_NAMES = {   # live name -> kernel name in `rocprofv3 --kernel-trace --stats` output (k=128: V=4, 32 lanes/row)

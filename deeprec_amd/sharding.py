@@ -260,6 +260,57 @@ def all_gather_table(T, group=None):
     return full[:T.rows].contiguous()
 
 
+def fetch_rows(ops, T, ids, group=None):
+    """Rows `ids` (GLOBAL row numbers, int32 [n]) of a ShardedTable, in the order given: ids -> owners, the owners
+    run the gather kernel on their shard, rows come back (one count exchange + host sync, two all-to-alls)."""
+    W = T.world
+    n = ids.numel()
+    if W == 1:
+        return ops.gather(T.w, ids)
+    order, cnt = ops.bucket_order((ids % W).to(torch.int32), W)       # stable bucket by owner
+    recv = torch.empty_like(cnt)
+    _a2a(recv, cnt, None, None, group)
+    sc, rc = torch.stack((cnt, recv)).tolist()
+    order = order.long()
+    local = torch.div(ids, W, rounding_mode="floor").to(torch.int32)[order].contiguous()
+    want = torch.empty(int(sum(rc)), dtype=torch.int32, device=ids.device)
+    _a2a(want, local, rc, sc, group)
+    served = ops.gather(T.w, want) if want.numel() else torch.empty((0, T.k), dtype=torch.float32, device=ids.device)
+    back = torch.empty((n, T.k), dtype=torch.float32, device=ids.device)
+    _a2a(back, served, sc, rc, group)
+    out = torch.empty_like(back)
+    out[order] = back                                                  # undo the bucketing
+    return out
+
+
+def sharded_eval_topk(ops, P, Q, users, K, train=None, targets=None, Q_full=None, group=None):
+    """Full-catalog top-K evaluation (RankingMetrics.py:82-101) with the USERS sharded data-parallel:
+    `users` = this rank's evaluation users (global ids; split them with shard_users), train / targets = their CSR
+    lists.  The item table is replicated with one all-gather (pass Q_full to reuse it across calls), the user rows
+    come from their owners, the MFMA scoring + top-K kernel runs locally.  Returns what ops.score_topk returns plus
+    the replicated item table."""
+    if Q_full is None:
+        Q_full = all_gather_table(Q, group)
+    U = fetch_rows(ops, P, users, group)
+    idx, val, rank = ops.score_topk(U, Q_full, K, train=train, targets=targets)
+    return idx, val, rank, Q_full
+
+
+def reduce_rank_metrics(ranks, K, group=None):
+    """Leave-one-out metrics from this rank's target ranks (one held-out item per user; -1 = not a candidate),
+    summed over all ranks: (users, hit-rate@K, NDCG@K, MRR).  One 4-float all-reduce."""
+    r = ranks.to(torch.float64)
+    ok = ranks >= 0
+    hit = ok & (ranks < K)
+    sums = torch.stack((ok.sum().to(torch.float64), hit.sum().to(torch.float64),
+                        torch.where(hit, 1.0 / torch.log2(r + 2.0), torch.zeros_like(r)).sum(),
+                        torch.where(ok, 1.0 / (r + 1.0), torch.zeros_like(r)).sum()))
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(sums, group=group)
+    n = max(float(sums[0]), 1.0)
+    return int(sums[0]), float(sums[1]) / n, float(sums[2]) / n, float(sums[3]) / n
+
+
 # ----------------------------------------------------------------------------------------------
 # sharded checkpoints (SURVEY 8f rank 4; the reference's save() is dead code, gmf.py:156-158, bprmf.py:164-166)
 # ----------------------------------------------------------------------------------------------

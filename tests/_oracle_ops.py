@@ -117,3 +117,20 @@ def init_normal_(w, seed, stddev, offset=0):
     full = co.init_normal(offset + w.numel(), seed, stddev)[offset:]
     w.copy_(torch.from_numpy(full).reshape(w.shape))
     return w
+
+
+def score_topk(U, I, K, train=None, targets=None):
+    """Oracle-backed stand-in for kernels.score_topk (dot scores): oracle/c_oracle.py:score_matrix +
+    oracle/ref_ops.py:topk_and_ranks per user."""
+    S = co.score_matrix(_n(U), _n(I), 0)
+    Nu = S.shape[0]
+    tp, ti = (_n(train[0]), _n(train[1])) if train is not None else (np.zeros(Nu + 1, np.int32), np.zeros(0, np.int32))
+    gp, gi = (_n(targets[0]), _n(targets[1])) if targets is not None else (np.zeros(Nu + 1, np.int32), np.zeros(0, np.int32))
+    idx = np.zeros((Nu, K), np.int32)
+    val = np.zeros((Nu, K), np.float32)
+    ranks = np.zeros(len(gi), np.int32)
+    for u in range(Nu):
+        top, tops, rk = ro.topk_and_ranks(S[u], ti[tp[u]:tp[u + 1]], gi[gp[u]:gp[u + 1]], K)
+        idx[u, :len(top)], val[u, :len(top)] = top, tops
+        ranks[gp[u]:gp[u + 1]] = rk
+    return torch.from_numpy(idx), torch.from_numpy(val), (torch.from_numpy(ranks) if targets is not None else None)

@@ -182,6 +182,20 @@ def test_world1_through_rccl_pipelined_equals_fused_step(dev):
     np.testing.assert_allclose(got[4], want[4], rtol=1e-6)
 
 
+def _stage_through_host(sh, dist):
+    def staged(o, inp, out_splits, in_splits, group, async_op=False):
+        oc = torch.empty(o.shape, dtype=o.dtype)              # gloo has no device all-to-all: stage through the host
+        dist.all_to_all_single(oc, inp.cpu(), out_splits, in_splits, group=group)
+        o.copy_(oc)
+
+        class Done:
+            def wait(self):
+                return True
+        return Done() if async_op else None
+
+    sh._a2a = staged
+
+
 def _worker2(rank, world, port, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -191,17 +205,7 @@ def _worker2(rank, world, port, out):
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
 
-        def staged(o, inp, out_splits, in_splits, group, async_op=False):
-            oc = torch.empty(o.shape, dtype=o.dtype)          # gloo has no device all-to-all: stage through the host
-            dist.all_to_all_single(oc, inp.cpu(), out_splits, in_splits, group=group)
-            o.copy_(oc)
-
-            class Done:
-                def wait(self):
-                    return True
-            return Done() if async_op else None
-
-        sh._a2a = staged
+        _stage_through_host(sh, dist)
         P0, Q0, batches = _case(33, 5001, 801, 64, 4096, 4)
         res = _train_sharded(rank, world, dev, P0, Q0, batches, pipelined=True)
         if rank == 0:
@@ -225,3 +229,83 @@ def test_two_ranks_on_one_gpu_equal_fused_step(dev, tmp_path, world):
     for nm, y in zip(("P", "Q", "vP", "vQ"), want[:4]):
         _same(res[nm], y, nm)
     np.testing.assert_allclose(res["losses"], want[4], rtol=1e-6)
+
+
+# ------------------------------------------------------------------ data-parallel evaluation
+def _eval_case():
+    rng = np.random.default_rng(41)
+    nu, ni, k = 3001, 2500, 64
+    P = rng.standard_normal((nu, k)).astype(np.float32)
+    Q = rng.standard_normal((ni, k)).astype(np.float32)
+    users = rng.permutation(nu)[:300].astype(np.int32)
+    train = [np.sort(rng.choice(ni, 50, replace=False)).astype(np.int32) for _ in users]
+    tgt = rng.integers(0, ni, len(users)).astype(np.int32)
+    return P, Q, users, train, tgt
+
+
+def _csr_of(lists):
+    ptr = np.concatenate(([0], np.cumsum([len(t) for t in lists]))).astype(np.int32)
+    idx = np.concatenate(list(lists) + [np.zeros(0, np.int32)]).astype(np.int32)
+    return ptr, idx
+
+
+def _eval_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deeprec_amd import kernels as K
+        from deeprec_amd import sharding as sh
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        _stage_through_host(sh, dist)
+        sh.all_gather_table = lambda T_, group=None: _gather_table_via_host(T_, dist)
+        P, Q, users, train, tgt = _eval_case()
+        k = P.shape[1]
+        Pt = sh.ShardedTable(P.shape[0], k, world, rank, dev)
+        Qt = sh.ShardedTable(Q.shape[0], k, world, rank, dev)
+        Pt.load_global(T(P, dev))
+        Qt.load_global(T(Q, dev))
+        lo, hi = sh.shard_users(len(users), world, rank)
+        tp, ti = _csr_of(train[lo:hi])
+        gp = np.arange(hi - lo + 1, dtype=np.int32)
+        idx, val, rk, _ = sh.sharded_eval_topk(K, Pt, Qt, T(users[lo:hi], dev), 10, train=(T(tp, dev), T(ti, dev)),
+                                               targets=(T(gp, dev), T(tgt[lo:hi], dev)))
+        m = sh.reduce_rank_metrics(rk.cpu(), 10)
+        parts = [None] * world
+        dist.all_gather_object(parts, (N(idx), N(val), N(rk)))
+        if rank == 0:
+            np.savez(out, idx=np.concatenate([p[0] for p in parts]), val=np.concatenate([p[1] for p in parts]),
+                     rk=np.concatenate([p[2] for p in parts]), m=np.array(m, dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gather_table_via_host(T_, dist):
+    per = (T_.rows + T_.world - 1) // T_.world
+    pad = torch.zeros((per, T_.k), dtype=torch.float32)
+    pad[:T_.local_rows] = T_.w.cpu()
+    parts = [torch.empty_like(pad) for _ in range(T_.world)]
+    dist.all_gather(parts, pad)
+    return torch.stack(parts, 1).reshape(per * T_.world, T_.k)[:T_.rows].contiguous().to(T_.w.device)
+
+
+def test_sharded_eval_two_ranks_equals_single_gpu(dev, tmp_path):
+    """evaluation users sharded over 2 ranks (sharing the box's GPU), item table replicated, user rows fetched from
+    their owners: top-K ids, scores and target ranks are those of one dr_score_topk_f32 call over everything."""
+    import torch.multiprocessing as mp
+    from deeprec_amd import kernels as K
+    out = str(tmp_path / "ev.npz")
+    mp.spawn(_eval_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = np.load(out)
+    P, Q, users, train, tgt = _eval_case()
+    tp, ti = _csr_of(train)
+    gp = np.arange(len(users) + 1, dtype=np.int32)
+    U = K.gather(T(P, dev), T(users, dev))
+    idx, val, rk = K.score_topk(U, T(Q, dev), 10, train=(T(tp, dev), T(ti, dev)), targets=(T(gp, dev), T(tgt, dev)))
+    assert np.array_equal(res["idx"], N(idx)) and np.array_equal(res["rk"], N(rk))
+    assert np.array_equal(res["val"].view(np.uint32), N(val).view(np.uint32))
+    r = N(rk).astype(np.float64)
+    ok, hit = r >= 0, (r >= 0) & (r < 10)
+    want = [ok.sum(), hit.sum() / ok.sum(), (1 / np.log2(r[hit] + 2)).sum() / ok.sum(), (1 / (r[ok] + 1)).sum() / ok.sum()]
+    np.testing.assert_allclose(res["m"], want, rtol=1e-12)

@@ -129,3 +129,70 @@ def test_sharded_checkpoint_reshards(tmp_path, w_save, w_load):
             assert torch.equal(got[n].w, full[n][r::w_load])
             for j in range(2):
                 assert torch.equal(got[n].slots[j], slot[n][j][r::w_load])
+
+
+def _eval_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import _oracle_ops as ops
+        from deeprec_amd import sharding as sh
+        nu, ni, k, K_ = 53, 40, 8, 5
+        P, Q, users, train, tgt = _eval_case(nu, ni, k)
+        Pt = sh.ShardedTable(nu, k, world, rank, "cpu")
+        Qt = sh.ShardedTable(ni, k, world, rank, "cpu")
+        Pt.load_global(torch.from_numpy(P))
+        Qt.load_global(torch.from_numpy(Q))
+        lo, hi = sh.shard_users(len(users), world, rank)
+        tp = np.concatenate(([0], np.cumsum([len(t) for t in train[lo:hi]]))).astype(np.int32)
+        ti = np.concatenate(train[lo:hi] + [np.zeros(0, np.int32)]).astype(np.int32)
+        gp = np.arange(hi - lo + 1, dtype=np.int32)
+        idx, val, rk, _ = sh.sharded_eval_topk(ops, Pt, Qt, torch.from_numpy(users[lo:hi]), K_,
+                                               train=(torch.from_numpy(tp), torch.from_numpy(ti)),
+                                               targets=(torch.from_numpy(gp), torch.from_numpy(tgt[lo:hi])))
+        m = sh.reduce_rank_metrics(rk, K_)
+        parts = [None] * world
+        dist.all_gather_object(parts, (idx.numpy(), rk.numpy()))
+        if rank == 0:
+            np.savez(out, idx=np.concatenate([p[0] for p in parts]), rk=np.concatenate([p[1] for p in parts]),
+                     m=np.array(m, dtype=np.float64))
+    finally:
+        dist.destroy_process_group()
+
+
+def _eval_case(nu, ni, k):
+    rng = np.random.default_rng(9)
+    P = rng.standard_normal((nu, k)).astype(np.float32)
+    Q = rng.standard_normal((ni, k)).astype(np.float32)
+    users = rng.permutation(nu)[:37].astype(np.int32)
+    train = [np.sort(rng.choice(ni, rng.integers(0, 9), replace=False)).astype(np.int32) for _ in users]
+    tgt = rng.integers(0, ni, len(users)).astype(np.int32)
+    return P, Q, users, train, tgt
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_eval_equals_single_process(tmp_path, world):
+    """users sharded data-parallel, item table all-gathered, user rows fetched from their owners: the same top-K
+    lists, target ranks and metric sums as one process over the whole tables."""
+    out = str(tmp_path / "ev.npz")
+    mp.spawn(_eval_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = np.load(out)
+    P, Q, users, train, tgt = _eval_case(53, 40, 8)
+    K_ = 5
+    S = (P[users].astype(np.float64) @ Q.T.astype(np.float64))
+    from oracle import c_oracle as co
+    S = co.score_matrix(P[users], Q, 0)
+    hits = ndcg = mrr = n = 0
+    for x in range(len(users)):
+        top, _, rk = ro.topk_and_ranks(S[x], train[x], [tgt[x]], K_)
+        assert np.array_equal(res["idx"][x][:len(top)], top)
+        assert res["rk"][x] == rk[0]
+        if rk[0] >= 0:
+            n += 1
+            mrr += 1.0 / (rk[0] + 1)
+            if rk[0] < K_:
+                hits += 1
+                ndcg += 1.0 / np.log2(rk[0] + 2)
+    np.testing.assert_allclose(res["m"], [n, hits / n, ndcg / n, mrr / n], rtol=1e-12)
