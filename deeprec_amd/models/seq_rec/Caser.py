@@ -10,12 +10,32 @@ SeqRecMetrics.evaluate_caser (MFMA scoring with item bias).
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate_caser
 from .._common import TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
 from ._seq_common import SeqBase
+
+
+def caser_convs(e, conv_v_w, conv_v_b, conv_h_w, conv_h_b):
+    """Caser.py:118-172 on e = Q[item_seq] [B,L,d]: the vertical convolution (n_v filters [L,1]) and the L horizontal
+    ones (n_h filters [h,d], ReLU, max over positions), concatenated [B, n_v*d + n_h*L].
+
+    Written as GEMMs (rocBLAS) instead of conv2d: every filter height is a different convolution shape, and MIOpen
+    searches and compiles a solver per shape and direction on first use (48 s for L = 5 on a fresh MI355X box, minutes
+    for L = 50).  Horizontal filter of height h: G = e @ W_h^T gives every (position, filter row) product, and the
+    window sum out[b,t,c] = sum_r G[b,t+r,c,r] is a strided view of G summed over r."""
+    B, L, d = e.shape
+    n_v = conv_v_w.shape[0]
+    out_v = torch.matmul(conv_v_w[:, 0, :, 0], e) + conv_v_b[None, :, None]          # [n_v,L] @ [B,L,d] -> [B,n_v,d]
+    outs = [out_v.permute(0, 2, 1).reshape(B, n_v * d)]                               # TF layout [B,d,n_v] flattened
+    for w, b in zip(conv_h_w, conv_h_b):
+        n_h, h = w.shape[0], w.shape[2]
+        G = torch.matmul(e, w[:, 0].reshape(n_h * h, d).t()).contiguous()             # [B,L,n_h*h]
+        s0, s1, _ = G.stride()
+        win = G.as_strided((B, L - h + 1, n_h, h), (s0, s1, h, s1 + 1))               # [b,t,c,r] -> G[b,t+r,c,r]
+        outs.append(torch.relu(win.sum(3) + b).max(1)[0])                             # [B,n_h]
+    return torch.cat(outs, 1)
 
 
 class Caser(SeqBase):
@@ -58,14 +78,7 @@ class Caser(SeqBase):
 
     def _user_emb(self, item_seq, user_id):
         """Caser.py:98-185 -> x = concat[z, p_u]  [B, 2d]."""
-        e = self.Q.lookup(item_seq)[:, None, :, :]                       # [B,1,L,d]  (NCHW view of NHWC [B,L,d,1])
-        out_v = F.conv2d(e, self.conv_v_w, self.conv_v_b)                 # [B,n_v,1,d]
-        out_v = out_v[:, :, 0, :].permute(0, 2, 1).reshape(-1, self.fc1_dim_v)   # TF layout [B,d,n_v] flattened
-        outs = []
-        for w, b in zip(self.conv_h_w, self.conv_h_b):
-            c = torch.relu(F.conv2d(e, w, b)[:, :, :, 0])                # [B,n_h,L-i+1]
-            outs.append(c.max(2)[0])
-        out = torch.cat([out_v] + outs, 1)
+        out = caser_convs(self.Q.lookup(item_seq), self.conv_v_w, self.conv_v_b, self.conv_h_w, self.conv_h_b)
         z = torch.relu(out @ self.full_w + self.full_b)
         return torch.cat((z, self.P.lookup(user_id)), 1)
 

@@ -170,3 +170,36 @@ def test_oracle_internal_consistency():
     assert abs(lc - loss) <= 1e-5 * abs(loss)
     np.testing.assert_allclose(Pc, Pr, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(Qc, Qr, rtol=1e-4, atol=1e-6)
+
+
+def test_caser_convs_equal_conv2d():
+    """deeprec_amd/models/seq_rec/Caser.py:caser_convs (GEMM form) against the literal conv2d form of
+    Caser.py:118-172, forward and gradients, on CPU."""
+    import torch
+    import torch.nn.functional as F
+    from deeprec_amd.models.seq_rec.Caser import caser_convs
+    torch.manual_seed(0)
+    B, L, d, n_v, n_h = 7, 6, 10, 3, 4
+    e = torch.randn(B, L, d, dtype=torch.float64, requires_grad=True)
+    vw = torch.randn(n_v, 1, L, 1, dtype=torch.float64, requires_grad=True)
+    vb = torch.randn(n_v, dtype=torch.float64, requires_grad=True)
+    hw = [torch.randn(n_h, 1, h, d, dtype=torch.float64, requires_grad=True) for h in range(1, L + 1)]
+    hb = [torch.randn(n_h, dtype=torch.float64, requires_grad=True) for _ in range(L)]
+
+    def literal():
+        x = e[:, None]
+        ov = F.conv2d(x, vw, vb)[:, :, 0, :].permute(0, 2, 1).reshape(B, n_v * d)
+        outs = [ov]
+        for w, b in zip(hw, hb):
+            outs.append(torch.relu(F.conv2d(x, w, b)[:, :, :, 0]).max(2)[0])
+        return torch.cat(outs, 1)
+
+    params = [e, vw, vb] + hw + hb
+    a = caser_convs(e, vw, vb, hw, hb)
+    b = literal()
+    assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+    coef = torch.randn_like(a)
+    ga = torch.autograd.grad((a * coef).sum(), params)
+    gb = torch.autograd.grad((b * coef).sum(), params)
+    for x, y in zip(ga, gb):
+        assert torch.allclose(x, y, rtol=1e-10, atol=1e-12)
