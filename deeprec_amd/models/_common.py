@@ -90,6 +90,54 @@ def to_dev(a, dtype, device):
 
 
 # ----------------------------------------------------------------------------------------------
+# launch-bound small-batch steps: replay them as one hipGraph
+# ----------------------------------------------------------------------------------------------
+class GraphedStep:
+    """A fixed-shape training step (the reference's B = 128 .. 1000 steps are 50-100 short launches: lookups, a few
+    small GEMMs under autograd, segment plans, optimizer applications) replayed as ONE hipGraph.
+
+    Call 1 runs `fn` eagerly (lazily created state -- optimizer slots, dense-gradient buffers, BLAS handles --
+    comes into being); call 2 copies its arguments into static buffers, captures `fn` on them (capture executes
+    nothing) and replays; later calls copy and replay.  Same kernels on the same data in the same order, so results
+    are bit-identical to the eager loop.  Only for steps whose host side is stateless from step to step (Adagrad /
+    RMSProp / SGD; Adam's bias correction is a per-step host scalar).  Falls back to eager for good when the shapes
+    change, capture fails, or DR_NO_GRAPH is set."""
+
+    def __init__(self, fn):
+        import os
+        self.fn, self.graph, self.calls = fn, None, 0
+        self.off = os.environ.get("DR_NO_GRAPH") is not None
+        self.static, self.out = None, None
+
+    def __call__(self, *tensors):
+        if self.off:
+            return self.fn(*tensors)
+        self.calls += 1
+        if self.calls == 1:
+            return self.fn(*tensors)
+        if self.graph is None:
+            try:
+                self.static = [t.clone() for t in tensors]
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out = self.fn(*self.static)
+                self.graph = g
+            except Exception:
+                self.off = True
+                torch.cuda.synchronize()
+                return self.fn(*tensors)
+        elif any(s.shape != t.shape or s.dtype != t.dtype for s, t in zip(self.static, tensors)):
+            self.off = True
+            return self.fn(*tensors)
+        else:
+            for s, t in zip(self.static, tensors):
+                s.copy_(t)
+        self.graph.replay()
+        return self.out
+
+
+# ----------------------------------------------------------------------------------------------
 # optimizer state with TensorFlow semantics ([TF-ext]; hyper-parameters cited in the model files)
 # ----------------------------------------------------------------------------------------------
 class TFOptimizer:

@@ -16,7 +16,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import NegItems, TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, NegItems, TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
 
 
 class NeuMF(object):
@@ -62,6 +62,7 @@ class NeuMF(object):
             self.kernels.append(W.requires_grad_(True))
             self.biases.append(b.requires_grad_(True))
         self.optimizer = TFOptimizer("adagrad", self.learning_rate)
+        self._step = GraphedStep(self.train_op)      # B = 256 steps are launch-bound: one hipGraph per step
         return self
 
     def _mlp(self, x):
@@ -123,7 +124,7 @@ class NeuMF(object):
         for i in range(self.total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)
-            loss = self.train_op(u_d[s], i_d[s], y_d[s])
+            loss = self._step(u_d[s], i_d[s], y_d[s])
             if i % self.display_step == 0:
                 if self.verbose:
                     print("Index: %04d; cost= %.9f" % (i + 1, float(loss.item())))

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from ... import kernels as K
-from .._common import TFOptimizer, Table, bi_interaction, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, TFOptimizer, Table, bi_interaction, device_of, normal_, shift_sess, to_dev
 
 
 class NFM():
@@ -45,6 +45,7 @@ class NFM():
         self.W1 = get("W1", lambda: normal_((num_factor, num_hidden), 1.0, dev)).requires_grad_(True)
         self.b1 = get("b1", lambda: normal_((num_hidden,), 1.0, dev)).requires_grad_(True)
         self.optimizer = TFOptimizer("adagrad", self.learning_rate)
+        self._step = GraphedStep(self.train_op)      # B = 128 steps are launch-bound: one hipGraph per step
 
     def _forward(self, feats, drop_mask=None):
         fm = bi_interaction(self.feature_embeddings, feats)
@@ -91,7 +92,7 @@ class NFM():
         for i in range(total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)
-            loss = self.train_op(x_d[s].contiguous(), y_d[s])
+            loss = self._step(x_d[s].contiguous(), y_d[s])
             if i % self.display_step == 0:
                 reg = self.reg_rate * 0.5 * float((self.feature_embeddings.w ** 2).sum())
                 print("Index: %04d; cost= %.9f" % (i + 1, float(loss.item()) + reg))

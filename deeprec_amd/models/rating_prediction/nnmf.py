@@ -11,7 +11,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RatingMetrics import MAE, RMSE
-from .._common import TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
 
 
 class NNMF():
@@ -46,6 +46,7 @@ class NNMF():
             self.kernels.append(W.requires_grad_(True))
             self.biases.append(b.requires_grad_(True))
         self.optimizer = TFOptimizer("rmsprop", self.learning_rate, eps=1e-10)
+        self._step = GraphedStep(self.train_op)
 
     def _forward(self, u, i):
         x = torch.cat((self.P.lookup(u), self.Q.lookup(i), self.U.lookup(u) * self.V.lookup(i)), 1)
@@ -82,7 +83,7 @@ class NNMF():
         for i in range(total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)
-            loss = self.train_op(u_d[s], i_d[s], y_d[s])
+            loss = self._step(u_d[s], i_d[s], y_d[s])
             if i % self.display_step == 0:
                 print("Index: %04d; cost= %.9f" % (i + 1, float(loss.item())))
                 if self.show_time:

@@ -13,7 +13,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate1
-from .._common import TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
 from ._seq_common import SeqBase
 
 
@@ -67,6 +67,7 @@ class AttRec(SeqBase):
             Wp = (torch.rand((d, d), device=dev) * 2 - 1) * lim
         self.linear_project = Wp.requires_grad_(True)
         self.optimizer = TFOptimizer("adagrad", self.learning_rate, initial_accumulator_value=0.05)
+        self._step = GraphedStep(self.train_op)
         return self
 
     def _seq_out(self, item_seq):

@@ -54,10 +54,11 @@ class SeqBase:
         s_d = to_dev(seq_r, torch.int32, dev)
         t_d = to_dev(tar_r, torch.int32, dev)
         n_d = to_dev(neg_r, torch.int32, dev)
+        step = getattr(self, "_step", None) or self.train_op
         for i in range(self.total_batch):
             start_time = time.time()
             sl = slice(i * self.batch_size, (i + 1) * self.batch_size)
-            loss = self.train_op(u_d[sl].contiguous(), s_d[sl].contiguous(), t_d[sl].contiguous(), n_d[sl].contiguous())
+            loss = step(u_d[sl].contiguous(), s_d[sl].contiguous(), t_d[sl].contiguous(), n_d[sl].contiguous())
             if i % self.display_step == 0:
                 if self.verbose:
                     print("Index: %04d; cost= %.9f" % (i + 1, float(loss.item())))

@@ -467,3 +467,45 @@ def test_drivers_run_on_synthetic_data(dev, driver, argv):
         if isinstance(t, torch.Tensor) and t.is_floating_point() and t.dim() == 2:
             tabs.append(t)
     assert tabs and all(bool(torch.isfinite(t).all()) for t in tabs)
+
+
+def test_graphed_step_equals_eager_loop(dev):
+    """_common.GraphedStep (one hipGraph per fixed-shape training step, used by NeuMF / NFM / NNMF / AttRec train()):
+    the replayed steps leave exactly the weights the eager loop leaves."""
+    from deeprec_amd.models._common import GraphedStep
+    from deeprec_amd.models.item_ranking.neumf import NeuMF
+    from deeprec_amd.models.rating_prediction.nfm import NFM
+    rng = np.random.default_rng(11)
+    t = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+
+    def neumf():
+        torch.manual_seed(0)
+        m = quiet(NeuMF, None, 300, 200, 0.5, 0.01, 1, 256)
+        m.build_network()
+        return m, lambda mm: [mm.P.w, mm.Q.w, mm.mlp_P.w, mm.mlp_Q.w] + list(mm.kernels) + list(mm.biases)
+    nb = [(t(rng.integers(0, 300, 256)), t(rng.zipf(1.3, 256) % 200), t(rng.integers(0, 2, 256), torch.float32)) for _ in range(6)]
+
+    def nfm():
+        torch.manual_seed(0)
+        m = quiet(NFM, None, 957, 4082, 0.05, 0.01, 1, 128)
+        m.build_network(500, 64, 64)
+        return m, lambda mm: [mm.feature_embeddings.w, mm.feature_bias.w, mm.W1, mm.b1, mm.pred_weight, mm.bias]
+    mask = t((rng.random((128, 64)) < 0.8), torch.float32)
+    fb = [(t(rng.integers(0, 500, (128, 10))), t(rng.choice([-1.0, 1.0], (128, 1)), torch.float32), mask) for _ in range(6)]
+
+    for make, batches in ((neumf, nb), (nfm, fb)):
+        a, params = make()
+        start = [x.detach().clone() for x in params(a)]
+        for b in batches:
+            la = a.train_op(*b)
+        g, _ = make()
+        with torch.no_grad():
+            for x, w0 in zip(params(g), start):             # same starting point (random init differs per build)
+                x.copy_(w0)
+        step = GraphedStep(g.train_op)
+        for b in batches:
+            lg = step(*b)
+        assert step.graph is not None and not step.off, "the step was not captured"
+        for x, y in zip(params(a), params(g)):
+            assert torch.equal(x.detach(), y.detach())
+        assert float(la) == float(lg)
