@@ -182,6 +182,95 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
     }
 }
 
+// Whole plan tail in ONE workgroup for small lists (the reference's batch sizes: B = 128 .. 1024, i.e. a few hundred
+// to a few thousand keys): block radix sort of (key, position), run heads, their scan, segment table, split index
+// and the long-segment list.  The general path is ~15 launches of 3-8 us each -- for 3072 keys all of it latency.
+// Same outputs as plan_finish (sorted positions, uniq, seg_start, hdr, long lists); the sort is stable, so they
+// are identical to the general path's.
+constexpr int SMALL_T = 1024, SMALL_IPT = 4, SMALL_N = SMALL_T * SMALL_IPT;
+__global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __restrict__ keys_in, int n,
+                                                              unsigned end_bit, uint32_t split_key,
+                                                              int32_t* __restrict__ vals_out,
+                                                              int32_t* __restrict__ uniq, int32_t* __restrict__ seg_start,
+                                                              int32_t* __restrict__ hdr, int32_t* __restrict__ long_seg,
+                                                              int32_t* __restrict__ long_cb,
+                                                              int32_t* __restrict__ part_owner) {
+    using Sort = rocprim::block_radix_sort<uint32_t, SMALL_T, SMALL_IPT, int32_t>;
+    using Scan = rocprim::block_scan<int, SMALL_T>;
+    __shared__ union {
+        typename Sort::storage_type sort;
+        typename Scan::storage_type scan;
+    } tmp;
+    __shared__ uint32_t sk[SMALL_N];
+    __shared__ int sh_split, sh_nlong, sh_parts;
+    const int tid = threadIdx.x;
+    // padding keys carry the largest value the sorted bits can hold and positions >= n: the sort is stable, so
+    // they end up behind every real entry
+    const uint32_t pad = end_bit >= 32 ? 0xFFFFFFFFu : ((1u << end_bit) - 1u);
+    uint32_t key[SMALL_IPT];
+    int32_t val[SMALL_IPT];
+#pragma unroll
+    for (int q = 0; q < SMALL_IPT; ++q) {
+        const int e = tid * SMALL_IPT + q;
+        key[q] = e < n ? keys_in[e] : pad;
+        val[q] = e;
+    }
+    Sort().sort(key, val, tmp.sort, 0u, end_bit);
+#pragma unroll
+    for (int q = 0; q < SMALL_IPT; ++q) {
+        const int e = tid * SMALL_IPT + q;
+        sk[e] = key[q];
+        if (e < n) vals_out[e] = val[q];
+    }
+    if (tid == 0) {
+        sh_nlong = 0;
+        sh_parts = 0;
+    }
+    __syncthreads();
+    int flag[SMALL_IPT], cnt = 0;
+#pragma unroll
+    for (int q = 0; q < SMALL_IPT; ++q) {
+        const int e = tid * SMALL_IPT + q;
+        flag[q] = (e < n && (e == 0 || sk[e] != sk[e - 1])) ? 1 : 0;
+        cnt += flag[q];
+    }
+    int base = 0, nseg = 0;
+    Scan().exclusive_scan(cnt, base, 0, nseg, tmp.scan);
+    if (tid == 0) sh_split = nseg;  // no segment at / above the split unless one is found below
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SMALL_IPT; ++q) {
+        const int e = tid * SMALL_IPT + q;
+        if (flag[q]) {
+            uniq[base] = (int32_t)sk[e];
+            seg_start[base] = e;
+            if (sk[e] >= split_key && (e == 0 || sk[e - 1] < split_key)) sh_split = base;
+            ++base;
+        }
+    }
+    if (tid == 0) seg_start[nseg] = n;
+    __threadfence_block();
+    __syncthreads();
+    for (int s = tid; s < nseg; s += SMALL_T) {
+        const int len = seg_start[s + 1] - seg_start[s];
+        if (len > LONG_SEG) {
+            const int l = atomicAdd(&sh_nlong, 1);
+            const int nch = (len + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK;
+            const int cb = atomicAdd(&sh_parts, nch);
+            long_seg[l] = s;
+            long_cb[l] = cb;
+            for (int c = 0; c < nch; ++c) part_owner[cb + c] = l;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        hdr[0] = nseg;
+        hdr[1] = sh_nlong;
+        hdr[2] = sh_parts;
+        hdr[3] = sh_split;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // segment sum (+ optimizer application)
 // ---------------------------------------------------------------------------------------
@@ -611,6 +700,14 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
     int32_t* segidx = (int32_t*)(base + L.segidx);
     int32_t* uniq = (int32_t*)(base + L.uniq);
     int32_t* seg_start = (int32_t*)(base + L.seg_start);
+    static const bool no_small = getenv("DR_NO_SMALL_PLAN") != nullptr;
+    if (n <= SMALL_N && !no_small) {
+        DR_LAUNCH(plan_small_kernel, dim3(1), dim3(SMALL_T), 0, st, (const uint32_t*)keys_in, (int)n, end_bit, split_key,
+                  vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg), (int32_t*)(base + L.long_cb),
+                  (int32_t*)(base + L.part_owner));
+        DR_CHECK_LAUNCH("plan_small_kernel");
+        return DR_OK;
+    }
     const int grid = grid_for(n, 256);
     size_t tb = (size_t)L.temp_bytes;
     DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, keys_in, keys_out, vals_in,

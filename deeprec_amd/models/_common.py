@@ -202,14 +202,40 @@ class TFOptimizer:
         K.sparse_row_update(table.w, s0, s1, ids.contiguous(), rows.contiguous(), self.params(reg, reg_mode))
 
 
-class Table:
-    """An embedding table [rows, k] (or a [rows] vector) living in HBM."""
+class Shard:
+    """Placement of row-sharded tables in a data-parallel model: global row r of every table
+    lives on rank r % world at local row r // world; each rank feeds its own slice of the batch."""
 
-    def __init__(self, w):
+    def __init__(self, world=1, rank=0, group=None):
+        self.world, self.rank, self.group = int(world), int(rank), group
+
+    def local_rows(self, rows):
+        return (rows - self.rank + self.world - 1) // self.world
+
+    def take(self, full):
+        """This rank's rows of a replicated array / tensor."""
+        return full[self.rank::self.world]
+
+    def all_reduce_grads(self, params):
+        """Data-parallel dense weights: sum the per-rank gradients (KB-sized; one all-reduce per tensor)."""
+        if self.world > 1:
+            import torch.distributed as dist
+            for p in params:
+                if p.grad is not None:
+                    dist.all_reduce(p.grad, group=self.group)
+
+
+class Table:
+    """An embedding table [rows, k] (or a [rows] vector) living in HBM.  With `shard` (world > 1), `w` is this
+    rank's shard: lookups fetch rows from their owners and the backward sends gradient rows to them, where they are
+    recorded like local ones (deeprec_amd/sharding.py:RowRoute), so the optimizer code is the same."""
+
+    def __init__(self, w, shard=None):
         self.w = w.contiguous()
         self.pending = []
         self._g = None
         self._hook = torch.zeros((), device=w.device, requires_grad=True)
+        self.shard = shard if (shard is not None and shard.world > 1) else None
 
     @property
     def k(self):
@@ -223,7 +249,35 @@ class Table:
 
     def lookup(self, ids):
         """tf.nn.embedding_lookup with the HIP gather; differentiable (backward is recorded for apply_table)."""
+        if self.shard is not None:
+            return _ShardedLookup.apply(self._hook, self, ids)
         return _Lookup.apply(self._hook, self, ids)
+
+
+class _ShardedLookup(torch.autograd.Function):
+    """Lookup of GLOBAL ids in a row-sharded table: ids -> owners, owners gather (K1), rows back; the backward
+    sends one gradient row per id to the owner, which records it for apply_table in canonical order."""
+
+    @staticmethod
+    def forward(ctx, hook, table, ids):
+        from .. import sharding as sh
+        flat = ids.reshape(-1)
+        if flat.dtype != torch.int32:
+            flat = flat.to(torch.int32)
+        rt = sh.RowRoute(K, flat.contiguous(), table.shard.world, table.shard.group)
+        vec = table.w.dim() == 1
+        k = 1 if vec else table.w.shape[1]
+        served = K.gather(table.w, rt.want) if rt.want.numel() else torch.empty((0,) + (() if vec else (k,)),
+                                                                                dtype=torch.float32, device=ids.device)
+        ctx.table, ctx.rt = table, rt
+        return rt.fetch(served).reshape(tuple(ids.shape) + (() if vec else (k,)))
+
+    @staticmethod
+    def backward(ctx, gout):
+        t, rt = ctx.table, ctx.rt
+        g = gout.reshape(rt.n, -1) if t.w.dim() == 2 else gout.reshape(-1)
+        t.pending.append((rt.want, rt.push(g.contiguous())))
+        return None, None, None
 
 
 class _Lookup(torch.autograd.Function):

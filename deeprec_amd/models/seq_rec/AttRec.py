@@ -32,8 +32,9 @@ def timing_signal(length, channels, device, min_timescale=1.0, max_timescale=1.0
 
 class AttRec(SeqBase):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.05, reg_rate=1e-2, epoch=5000, batch_size=1000,
-                 show_time=False, T=1, display_step=1000, verbose=False, device=None):
+                 show_time=False, T=1, display_step=1000, verbose=False, device=None, shard=None):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
+        self.shard = shard if (shard is not None and shard.world > 1) else None    # _common.Shard: DP over ranks
         self.learning_rate = learning_rate
         self.epochs = epoch
         self.batch_size = batch_size
@@ -53,10 +54,13 @@ class AttRec(SeqBase):
         init = init or {}
 
         def tab(n, rows, k, std):
+            sh = self.shard
             if n in init:
-                return Table(to_dev(init[n], torch.float32, dev))
+                w = to_dev(init[n], torch.float32, dev)
+                return Table(sh.take(w) if sh else w, sh)
+            rows = sh.local_rows(rows) if sh else rows
             w = normal_((rows, k) if k else (rows,), std, dev)
-            return Table(w.clamp_(-2 * std, 2 * std) if n in "PVQXA" else w)    # truncated normal: |x| <= 2 sigma
+            return Table(w.clamp_(-2 * std, 2 * std) if n in "PVQXA" else w, sh)    # truncated normal: |x| <= 2 sigma
         self.P, self.V = tab("P", self.num_user, d, 0.001), tab("V", self.num_user, d, 0.001)
         self.Q, self.X, self.A = tab("Q", self.num_item, d, 0.001), tab("X", self.num_item, d, 0.001), tab("A", self.num_item, d, 0.001)
         self.W, self.b = tab("W", self.num_item, 2 * d, 0.01), tab("b", self.num_item, 0, 0.01)
@@ -93,6 +97,8 @@ class AttRec(SeqBase):
         negative = self._distance(out, user_id, neg_item_id)
         loss = torch.clamp(target - negative + 0.5, min=0).sum()
         loss.backward()
+        if self.shard:
+            self.shard.all_reduce_grads([self.linear_project])
         o = self.optimizer
         o.begin_step()
         with torch.no_grad():

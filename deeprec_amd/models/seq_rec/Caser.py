@@ -40,8 +40,9 @@ def caser_convs(e, conv_v_w, conv_v_b, conv_h_w, conv_h_b):
 
 class Caser(SeqBase):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.001, reg_rate=1e-6, epoch=500, batch_size=1000,
-                 show_time=False, T=1, display_step=1000, verbose=False, device=None):
+                 show_time=False, T=1, display_step=1000, verbose=False, device=None, shard=None):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
+        self.shard = shard if (shard is not None and shard.world > 1) else None    # _common.Shard: DP over ranks
         self.learning_rate = learning_rate
         self.epochs = epoch
         self.batch_size = batch_size
@@ -58,7 +59,15 @@ class Caser(SeqBase):
         self.n_h, self.n_v, self.L, self.num_T, self.num_factor, self.num_neg = n_h, n_v, L, num_T, num_factor, num_neg
         dev, d = self.device, num_factor
         init = init or {}
-        tab = lambda n, shape: Table(to_dev(init[n], torch.float32, dev) if n in init else normal_(shape, 0.01, dev))
+        sh = self.shard
+
+        def tab(n, shape):
+            if n in init:
+                w = to_dev(init[n], torch.float32, dev)
+                return Table(sh.take(w) if sh else w, sh)
+            if sh:
+                shape = (sh.local_rows(shape[0]),) + tuple(shape[1:])
+            return Table(normal_(shape, 0.01, dev), sh)
         self.P, self.V = tab("P", (self.num_user, d)), tab("V", (self.num_user, d * L))
         self.Q, self.W, self.b = tab("Q", (self.num_item, d)), tab("W", (self.num_item, 2 * d)), tab("b", (self.num_item,))
         dense = lambda n, shape, std: (to_dev(init[n], torch.float32, dev) if n in init else
@@ -91,7 +100,11 @@ class Caser(SeqBase):
         x = self._user_emb(item_seq, user_id)
         target, negative = self._score(x, item_id), self._score(x, neg_item_id)
         loss = -torch.log(torch.sigmoid(target) + 1e-10).mean() - torch.log(1 - torch.sigmoid(negative) + 1e-10).mean()
+        if self.shard:
+            loss = loss / self.shard.world      # the loss is a batch MEAN: each rank holds 1/world of the batch
         loss.backward()
+        if self.shard:
+            self.shard.all_reduce_grads(self._dense_params())
         o = self.optimizer
         o.begin_step()
         with torch.no_grad():

@@ -58,6 +58,10 @@ class SeqBase:
         for i in range(self.total_batch):
             start_time = time.time()
             sl = slice(i * self.batch_size, (i + 1) * self.batch_size)
+            sh = getattr(self, "shard", None)
+            if sh:          # data-parallel: this rank's contiguous part of the batch (same permutation on every rank)
+                per = self.batch_size // sh.world
+                sl = slice(i * self.batch_size + sh.rank * per, i * self.batch_size + (sh.rank + 1) * per)
             loss = step(u_d[sl].contiguous(), s_d[sl].contiguous(), t_d[sl].contiguous(), n_d[sl].contiguous())
             if i % self.display_step == 0:
                 if self.verbose:

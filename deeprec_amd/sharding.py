@@ -260,27 +260,47 @@ def all_gather_table(T, group=None):
     return full[:T.rows].contiguous()
 
 
+class RowRoute:
+    """Routing of one id list (GLOBAL row numbers, int32 [n]) to the ranks that own the rows and back: a stable
+    bucket by owner, one count exchange + host synchronisation, the local row numbers to the owners (`want`).
+    fetch() brings rows back in the order of the id list; push() takes per-id rows (gradients) to the owners, where
+    they arrive source rank by source rank, each source's in the order of its id list -- i.e. in the order a single
+    process sees for the concatenation of every rank's list."""
+
+    def __init__(self, ops, ids, world, group=None):
+        self.world, self.group, self.n = world, group, ids.numel()
+        order, cnt = ops.bucket_order((ids % world).to(torch.int32), world)
+        recv = torch.empty_like(cnt)
+        _a2a(recv, cnt, None, None, group)
+        self.sc, self.rc = torch.stack((cnt, recv)).tolist()             # host sync: variable split sizes
+        self.order = order.long()
+        local = torch.div(ids, world, rounding_mode="floor").to(torch.int32)[self.order].contiguous()
+        self.want = torch.empty(int(sum(self.rc)), dtype=torch.int32, device=ids.device)
+        _a2a(self.want, local, self.rc, self.sc, group)
+
+    def fetch(self, served):
+        """served = owner-side rows for `want` [n_recv, ...] -> rows of the id list [n, ...]."""
+        back = torch.empty((self.n,) + tuple(served.shape[1:]), dtype=served.dtype, device=served.device)
+        _a2a(back, served.contiguous(), self.sc, self.rc, self.group)
+        out = torch.empty_like(back)
+        out[self.order] = back                                           # undo the bucketing
+        return out
+
+    def push(self, rows):
+        """rows per id [n, ...] -> owner-side rows [n_recv, ...] aligned with `want`."""
+        out = torch.empty((self.want.numel(),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        _a2a(out, rows[self.order].contiguous(), self.rc, self.sc, self.group)
+        return out
+
+
 def fetch_rows(ops, T, ids, group=None):
     """Rows `ids` (GLOBAL row numbers, int32 [n]) of a ShardedTable, in the order given: ids -> owners, the owners
     run the gather kernel on their shard, rows come back (one count exchange + host sync, two all-to-alls)."""
-    W = T.world
-    n = ids.numel()
-    if W == 1:
+    if T.world == 1:
         return ops.gather(T.w, ids)
-    order, cnt = ops.bucket_order((ids % W).to(torch.int32), W)       # stable bucket by owner
-    recv = torch.empty_like(cnt)
-    _a2a(recv, cnt, None, None, group)
-    sc, rc = torch.stack((cnt, recv)).tolist()
-    order = order.long()
-    local = torch.div(ids, W, rounding_mode="floor").to(torch.int32)[order].contiguous()
-    want = torch.empty(int(sum(rc)), dtype=torch.int32, device=ids.device)
-    _a2a(want, local, rc, sc, group)
-    served = ops.gather(T.w, want) if want.numel() else torch.empty((0, T.k), dtype=torch.float32, device=ids.device)
-    back = torch.empty((n, T.k), dtype=torch.float32, device=ids.device)
-    _a2a(back, served, sc, rc, group)
-    out = torch.empty_like(back)
-    out[order] = back                                                  # undo the bucketing
-    return out
+    rt = RowRoute(ops, ids, T.world, group)
+    served = ops.gather(T.w, rt.want) if rt.want.numel() else torch.empty((0, T.k), dtype=torch.float32, device=ids.device)
+    return rt.fetch(served)
 
 
 def sharded_eval_topk(ops, P, Q, users, K, train=None, targets=None, Q_full=None, group=None):

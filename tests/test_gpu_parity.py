@@ -91,8 +91,9 @@ def test_init_normal_matches_oracle(dev):
 
 
 # ------------------------------------------------------------------ K2
-@pytest.mark.parametrize("n,rows", [(0, 10), (1, 1), (5000, 37), (20000, 100000)])
-def test_segment_plan(dev, n, rows):
+@pytest.mark.parametrize("n,rows", [(0, 10), (1, 1), (2, 5), (300, 7), (3072, 2625), (4095, 100000), (4096, 3), (4097, 50),
+                                    (5000, 37), (20000, 100000)])
+def test_segment_plan(dev, n, rows):      # n <= 4096: the single-workgroup plan kernel; above: rocPRIM path
     from deeprec_amd import kernels as K
     rng = np.random.default_rng(n)
     ids = rng.integers(0, rows, n).astype(np.int32)
@@ -577,6 +578,28 @@ def test_score_topk_large_property(dev):
             r = rank[2 * u + x]
             if r >= 0:
                 assert (r < K_) == (t in idx[u])
+
+
+def test_small_plan_path_equals_general_path_in_updates(dev):
+    """A segment update planned by the one-workgroup kernel (n <= 4096) and the same update planned by the general
+    rocPRIM path (the list padded with out-of-range ids, which every kernel skips) leave identical rows; long
+    segments (> 4 contributions) and a 300-fold duplicate included."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(5)
+    rows, k, n = 500, 64, 4000
+    ids = (rng.zipf(1.3, n) % rows).astype(np.int32)
+    ids[:300] = 7
+    src = rng.standard_normal((n, k)).astype(np.float32)
+    pad = 200                                            # pushes the list over the small-path limit
+    ids_big = np.concatenate((ids, np.full(pad, -1, np.int32)))
+    src_big = np.concatenate((src, rng.standard_normal((pad, k)).astype(np.float32)))
+    a = torch.zeros((rows, k), device=dev)
+    b = torch.zeros((rows, k), device=dev)
+    K.scatter_add(a, T(ids, dev), T(src, dev))
+    K.scatter_add(b, T(ids_big, dev), T(src_big, dev))
+    assert torch.equal(a, b)
+    want = ro.scatter_add(np.zeros((rows, k), np.float32), ids, src)
+    assert np.array_equal(N(a).view(np.uint32), want.view(np.uint32))
 
 
 # ------------------------------------------------------------------ sharded step, real kernels, world 1

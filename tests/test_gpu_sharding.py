@@ -309,3 +309,120 @@ def test_sharded_eval_two_ranks_equals_single_gpu(dev, tmp_path):
     ok, hit = r >= 0, (r >= 0) & (r < 10)
     want = [ok.sum(), hit.sum() / ok.sum(), (1 / np.log2(r[hit] + 2)).sum() / ok.sum(), (1 / (r[ok] + 1)).sum() / ok.sum()]
     np.testing.assert_allclose(res["m"], want, rtol=1e-12)
+
+
+# ------------------------------------------------------------------ config 5: data-parallel AttRec / Caser
+def _seq_case(cls_name):
+    rng = np.random.default_rng(51)
+    nu, ni, L, T_, d, B = 400, 300, 6, 2, 32, 64
+    init = {}
+    if cls_name == "AttRec":
+        for n, r in (("P", nu), ("V", nu), ("Q", ni), ("X", ni), ("A", ni)):
+            init[n] = (rng.standard_normal((r, d)) * 0.05).astype(np.float32)
+        init["W"] = (rng.standard_normal((ni, 2 * d)) * 0.01).astype(np.float32)
+        init["b"] = (rng.standard_normal(ni) * 0.01).astype(np.float32)
+        init["linear_project"] = (rng.standard_normal((d, d)) * 0.2).astype(np.float32)
+        kw = dict(num_factor=d, num_neg=1)
+    else:
+        n_h, n_v = 4, 2
+        init["P"] = (rng.standard_normal((nu, d)) * 0.05).astype(np.float32)
+        init["V"] = (rng.standard_normal((nu, d * L)) * 0.05).astype(np.float32)
+        init["Q"] = (rng.standard_normal((ni, d)) * 0.05).astype(np.float32)
+        init["W"] = (rng.standard_normal((ni, 2 * d)) * 0.05).astype(np.float32)
+        init["b"] = (rng.standard_normal(ni) * 0.05).astype(np.float32)
+        init["conv_v_w"] = (rng.standard_normal((n_v, 1, L, 1)) * 0.3).astype(np.float32)
+        init["conv_v_b"] = np.zeros(n_v, np.float32)
+        for h in range(1, L + 1):
+            init["conv_h_w%d" % h] = (rng.standard_normal((n_h, 1, h, d)) * 0.1).astype(np.float32)
+            init["conv_h_b%d" % h] = np.zeros(n_h, np.float32)
+        init["full_w"] = (rng.standard_normal((n_v * d + n_h * L, d)) * 0.1).astype(np.float32)
+        init["full_b"] = np.zeros(d, np.float32)
+        kw = dict(num_factor=d, num_neg=1, n_h=n_h, n_v=n_v)
+    steps = []
+    for _ in range(3):
+        steps.append((rng.integers(0, nu, B).astype(np.int32), (rng.zipf(1.3, (B, L)) % (ni - 1) + 1).astype(np.int32),
+                      rng.integers(1, ni, (B, T_)).astype(np.int32), rng.integers(1, ni, (B, T_)).astype(np.int32)))
+    return nu, ni, L, T_, B, init, kw, steps
+
+
+def _seq_model(cls_name, dev, shard=None):
+    import contextlib
+    import io
+    from deeprec_amd.models.seq_rec.AttRec import AttRec
+    from deeprec_amd.models.seq_rec.Caser import Caser
+    nu, ni, L, T_, B, init, kw, steps = _seq_case(cls_name)
+    cls = AttRec if cls_name == "AttRec" else Caser
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = cls(None, nu, ni, 0.05 if cls is AttRec else 0.001, 0.01, 1, B, device=dev, shard=shard)
+        m.build_network(L, T_, init=init, **kw)
+    return m, steps
+
+
+def _seq_worker(rank, world, port, cls_name, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deeprec_amd import sharding as sh
+        from deeprec_amd.models._common import Shard
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        _stage_through_host(sh, dist)
+        shard = Shard(world, rank)
+        # dense gradients are all-reduced on the device: stage them through the host as well (gloo)
+        shard.all_reduce_grads = lambda params: [p.grad.copy_(_allreduce_host(dist, p.grad)) for p in params if p.grad is not None]
+        m, steps = _seq_model(cls_name, dev, shard)
+        per = len(steps[0][0]) // world
+        losses = []
+        for b in steps:
+            mine = tuple(T(x[rank * per:(rank + 1) * per], dev) for x in b)
+            l = m.train_op(*mine).cpu()
+            dist.all_reduce(l)
+            losses.append(float(l))
+        res = {}
+        names = [n for n in ("P", "V", "Q", "X", "W", "b") if hasattr(m, n)]
+        for n in names:
+            w = getattr(m, n).w.cpu()
+            rows = _seq_case(cls_name)[5][n].shape[0]
+            per_r = (rows + world - 1) // world
+            pad = torch.zeros((per_r,) + tuple(w.shape[1:]))
+            pad[:w.shape[0]] = w
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad)
+            res[n] = torch.stack(parts, 1).reshape((per_r * world,) + tuple(w.shape[1:]))[:rows].numpy()
+        dense = {"linear_project": m.linear_project} if cls_name == "AttRec" else {"full_w": m.full_w, "conv_v_w": m.conv_v_w,
+                                                                                  "conv_h_w3": m.conv_h_w[2]}
+        for n, p in dense.items():
+            res[n] = p.detach().cpu().numpy()
+        if rank == 0:
+            np.savez(out, losses=np.array(losses), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def _allreduce_host(dist, g):
+    c = g.cpu()
+    dist.all_reduce(c)
+    return c.to(g.device)
+
+
+@pytest.mark.parametrize("cls_name", ["AttRec", "Caser"])
+def test_data_parallel_seq_models_equal_single_gpu(dev, tmp_path, cls_name):
+    """BASELINE config 5: the batch split over 2 ranks (sharing the box's GPU), every table row-sharded (lookups fetch
+    rows from their owners, gradient rows go back and are applied in global batch order), the small dense weights
+    all-reduced: after 3 steps tables and dense weights equal the single-GPU model's on the whole batch (fp32
+    tolerance: the dense layers see other GEMM shapes per rank)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "seq.npz")
+    mp.spawn(_seq_worker, args=(2, _free_port(), cls_name, out), nprocs=2, join=True)
+    res = np.load(out)
+    m, steps = _seq_model(cls_name, dev)
+    losses = [float(m.train_op(*(T(x, dev) for x in b))) for b in steps]
+    np.testing.assert_allclose(res["losses"], losses, rtol=2e-5)
+    for n in ("P", "V", "Q", "X", "W", "b"):
+        if hasattr(m, n):
+            np.testing.assert_allclose(res[n], N(getattr(m, n).w), rtol=2e-4, atol=2e-6, err_msg=n)
+    dense = {"linear_project": m.linear_project} if cls_name == "AttRec" else {"full_w": m.full_w, "conv_v_w": m.conv_v_w,
+                                                                              "conv_h_w3": m.conv_h_w[2]}
+    for n, p in dense.items():
+        np.testing.assert_allclose(res[n], N(p), rtol=2e-4, atol=2e-6, err_msg=n)
