@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
 // and the long-segment list.  The general path is ~15 launches of 3-8 us each -- for 3072 keys all of it latency.
 // Same outputs as plan_finish (sorted positions, uniq, seg_start, hdr, long lists); the sort is stable, so they
 // are identical to the general path's.
-constexpr int SMALL_T = 1024, SMALL_IPT = 4, SMALL_N = SMALL_T * SMALL_IPT;
+constexpr int SMALL_IPT = 4, SMALL_N = 1024 * SMALL_IPT;
+template <int SMALL_T>  // 256 threads serve lists of <= 1024 keys (fewer, cheaper barriers), 1024 threads <= 4096
 __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __restrict__ keys_in, int n,
                                                               unsigned end_bit, uint32_t split_key,
                                                               int32_t* __restrict__ vals_out,
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
         typename Sort::storage_type sort;
         typename Scan::storage_type scan;
     } tmp;
-    __shared__ uint32_t sk[SMALL_N];
+    __shared__ uint32_t sk[SMALL_T * SMALL_IPT];
     __shared__ int sh_split, sh_nlong, sh_parts;
     const int tid = threadIdx.x;
     // padding keys carry the largest value the sorted bits can hold and positions >= n: the sort is stable, so
@@ -469,44 +470,87 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
     const int cpr = a.k / V;
     const int s_lo = (PART == 2) ? a.hdr[3] : 0;
     const int s_hi = (PART == 1) ? a.hdr[3] : a.hdr[0];
-    for (int s = s_lo + blockIdx.x * SPB + sub; s < s_hi; s += gridDim.x * SPB) {
-        const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
-        if ((int64_t)r >= a.rows) continue;  // sentinel segment of out-of-range ids / the other table's rows
-        const int b = a.seg_start[s], e = a.seg_start[s + 1];
-        if (e - b > LONG_SEG) continue;      // seg_long_kernel's
-        {
-            // resolve the <= 4 contributions once, then every vector column issues its source-row and
+    // Two-stage software pipeline over the segments of this sub-wave: a segment's rows are three dependent loads
+    // away from its index (segment table -> contribution list -> rows), so while segment i moves its rows, the
+    // contribution list of segment i+1 and the table entry of segment i+2 are already in flight.
+    const int stride = gridDim.x * SPB;
+    struct Seg {
+        uint32_t r;
+        int b, len;
+        bool go;
+    };
+    auto stage_a = [&](int s) {
+        Seg g;
+        g.go = s < s_hi;
+        g.r = 0;
+        g.b = 0;
+        g.len = 0;
+        if (g.go) {
+            g.r = (uint32_t)a.uniq[s] - a.id_lo;
+            g.b = a.seg_start[s];
+            g.len = a.seg_start[s + 1] - g.b;
+        }
+        return g;
+    };
+    // sentinel segment of out-of-range ids / the other table's rows; long segments are seg_long_kernel's
+    auto live = [&](const Seg& g) { return g.go && (int64_t)g.r < a.rows && g.len <= LONG_SEG; };
+    int s = s_lo + blockIdx.x * SPB + sub;
+    Seg g0 = stage_a(s), g1 = stage_a(s + stride);
+    int si0[4], sp0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        si0[q] = -1;
+        sp0[q] = 0;
+        if (live(g0) && q < g0.len) {
+            si0[q] = a.msrc[g0.b + q];
+            if (a.coef) sp0[q] = a.spos[g0.b + q];
+        }
+    }
+    while (g0.go) {
+        const Seg g2 = stage_a(s + 2 * stride);
+        int si1[4], sp1[4];
+        const bool live1 = live(g1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            si1[q] = -1;
+            sp1[q] = 0;
+            if (live1 && q < g1.len) {
+                si1[q] = a.msrc[g1.b + q];
+                if (a.coef) sp1[q] = a.spos[g1.b + q];
+            }
+        }
+        if (live(g0)) {
+            // the <= 4 contributions are resolved; every vector column issues its coefficient, source-row and
             // destination-row loads together (blocked order: a single block)
-            const int len = e - b;
-            int64_t si[4];
             float cf[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                si[q] = -1;
-                cf[q] = 1.0f;
-                if (q < len) {
-                    si[q] = a.msrc[b + q];
-                    if (a.coef) cf[q] = a.coef[a.spos[b + q] - a.pos_lo];
-                }
-            }
+            for (int q = 0; q < 4; ++q) cf[q] = (a.coef && si0[q] >= 0) ? a.coef[sp0[q] - a.pos_lo] : 1.0f;
             for (int c = lane; c < cpr; c += LPR) {
                 float v[4][V], tot[V];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (si[q] >= 0) vload<V>(v[q], a.src + si[q] * a.k + c * V);
+                    if (si0[q] >= 0) vload<V>(v[q], a.src + (int64_t)si0[q] * a.k + c * V);
 #pragma unroll
                 for (int x = 0; x < V; ++x) tot[x] = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (si[q] >= 0) {
+                    if (si0[q] >= 0) {
 #pragma unroll
                         for (int x = 0; x < V; ++x) tot[x] = tot[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
                     }
 #pragma unroll
                 for (int x = 0; x < V; ++x) tot[x] = 0.0f + tot[x];
-                apply_row<V, KIND>(a, r, c, tot);
+                apply_row<V, KIND>(a, g0.r, c, tot);
             }
         }
+        g0 = g1;
+        g1 = g2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            si0[q] = si1[q];
+            sp0[q] = sp1[q];
+        }
+        s += stride;
     }
 }
 
@@ -702,9 +746,14 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
     int32_t* seg_start = (int32_t*)(base + L.seg_start);
     static const bool no_small = getenv("DR_NO_SMALL_PLAN") != nullptr;
     if (n <= SMALL_N && !no_small) {
-        DR_LAUNCH(plan_small_kernel, dim3(1), dim3(SMALL_T), 0, st, (const uint32_t*)keys_in, (int)n, end_bit, split_key,
-                  vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg), (int32_t*)(base + L.long_cb),
-                  (int32_t*)(base + L.part_owner));
+        if (n <= 256 * SMALL_IPT)
+            DR_LAUNCH(plan_small_kernel<256>, dim3(1), dim3(256), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
+                      split_key, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
+                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner));
+        else
+            DR_LAUNCH(plan_small_kernel<1024>, dim3(1), dim3(1024), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
+                      split_key, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
+                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner));
         DR_CHECK_LAUNCH("plan_small_kernel");
         return DR_OK;
     }

@@ -85,6 +85,35 @@ def sample_uniform_negatives(users, neg, n_per_user=1):
     return out
 
 
+def device_pointwise_epoch(model):
+    """One epoch of (user, item, label) training triples for the pointwise models (gmf.py:100-124, neumf.py:153-180)
+    assembled on the device: num_neg_sample negatives per positive from dr_sample_negatives_i32 (uniform over the
+    user's unseen items, independent draws -- the reference's random.sample draws without replacement inside one
+    positive's group; with ~30 draws from thousands of candidates the two differ by a few repeated negatives),
+    label 0, then one device permutation.  Replaces the per-positive Python loop.
+    Returns int32 users, int32 items, float32 labels (device tensors, shuffled)."""
+    dev = model.device
+    if getattr(model, "_train_csr_dev", None) is None:
+        c = model.neg_items.csr
+        model._train_csr_dev = (to_dev(c.indptr, torch.int32, dev), to_dev(c.indices, torch.int32, dev))
+        model._pos_dev = (to_dev(np.asarray(model.user), torch.int32, dev), to_dev(np.asarray(model.item), torch.int32, dev),
+                          to_dev(np.asarray(model.label, dtype=np.float32), torch.float32, dev))
+    u, i, y = model._pos_dev
+    n_neg = int(model.num_neg_sample)
+    seed = int(np.random.randint(0, 2 ** 31 - 1))        # one host draw per epoch keeps np.random.seed() reproducible
+    neg = K.sample_negatives(*model._train_csr_dev, u, model.num_item, seed, n_neg=n_neg)      # [n_pos, n_neg]
+    users = torch.cat((u, u[:, None].expand(-1, n_neg).reshape(-1)))
+    items = torch.cat((i, neg.reshape(-1)))
+    labels = torch.cat((y, torch.zeros(neg.numel(), dtype=torch.float32, device=dev)))
+    keep = items >= 0                                      # a user who has seen every item has no negative (-1)
+    if not bool(keep.all()):
+        users, items, labels = users[keep], items[keep], labels[keep]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    perm = torch.randperm(users.numel(), device=dev, generator=gen)
+    return users[perm].contiguous(), items[perm].contiguous(), labels[perm].contiguous()
+
+
 def to_dev(a, dtype, device):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
 

@@ -11,12 +11,12 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import NegItems, TFOptimizer, device_of, normal_, shift_sess, to_dev
+from .._common import NegItems, TFOptimizer, device_of, device_pointwise_epoch, normal_, shift_sess, to_dev
 
 
 class GMF(object):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.5, reg_rate=0.01, epoch=500, batch_size=256,
-                 verbose=False, t=1, display_step=1000, device=None, reg_mode="dense"):
+                 verbose=False, t=1, display_step=1000, device=None, reg_mode="dense", sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
         self.learning_rate = learning_rate
         self.reg_rate = reg_rate
@@ -27,6 +27,9 @@ class GMF(object):
         self.display_step = display_step
         self.device = device_of(device)
         self.reg_mode = {"dense": K.REG_DENSE, "touched": K.REG_TOUCHED}[reg_mode]
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device'")
+        self.sampler = sampler
         self.num_neg_sample = None
         self.P = None
         self.Q = None
@@ -90,10 +93,15 @@ class GMF(object):
                                 self.optimizer.params(self.reg_rate, self.reg_mode), ws=self._ws)
 
     def train(self):
-        user_random, item_random, labels_random = self._sample_epoch()
-        u_d = to_dev(user_random, torch.int32, self.device)
-        i_d = to_dev(item_random, torch.int32, self.device)
-        y_d = to_dev(labels_random, torch.float32, self.device)
+        if self.sampler == "device":
+            u_d, i_d, y_d = device_pointwise_epoch(self)
+            self.num_training = u_d.numel()
+            self.total_batch = int(self.num_training / self.batch_size)
+        else:
+            user_random, item_random, labels_random = self._sample_epoch()
+            u_d = to_dev(user_random, torch.int32, self.device)
+            i_d = to_dev(item_random, torch.int32, self.device)
+            y_d = to_dev(labels_random, torch.float32, self.device)
         for i in range(self.total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)

@@ -16,12 +16,12 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import GraphedStep, NegItems, TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, NegItems, TFOptimizer, device_pointwise_epoch, Table, device_of, normal_, shift_sess, to_dev
 
 
 class NeuMF(object):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.5, reg_rate=0.01, epoch=500, batch_size=256,
-                 verbose=False, t=1, display_step=1000, device=None):
+                 verbose=False, t=1, display_step=1000, device=None, sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
         self.learning_rate = learning_rate
         self.reg_rate = reg_rate
@@ -31,6 +31,9 @@ class NeuMF(object):
         self.T = t
         self.display_step = display_step
         self.device = device_of(device)
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device'")
+        self.sampler = sampler
         self.num_neg_sample = None
         self.test_data = None
         self.user = None
@@ -106,6 +109,11 @@ class NeuMF(object):
 
     def train(self):
         """neumf.py:153-192."""
+        if self.sampler == "device":
+            u_d, i_d, y_d = device_pointwise_epoch(self)
+            self.num_training = u_d.numel()
+            self.total_batch = int(self.num_training / self.batch_size)
+            return self._run_epoch(u_d, i_d, y_d)
         user_append, item_append = [], []
         for u in self.user:
             cand = self.neg_items[u]
@@ -121,6 +129,9 @@ class NeuMF(object):
         u_d = to_dev(user_temp[idxs], torch.int32, self.device)
         i_d = to_dev(item_temp[idxs], torch.int32, self.device)
         y_d = to_dev(labels_temp[idxs], torch.float32, self.device)
+        return self._run_epoch(u_d, i_d, y_d)
+
+    def _run_epoch(self, u_d, i_d, y_d):
         for i in range(self.total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)

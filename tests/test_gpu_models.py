@@ -509,3 +509,29 @@ def test_graphed_step_equals_eager_loop(dev):
         for x, y in zip(params(a), params(g)):
             assert torch.equal(x.detach(), y.detach())
         assert float(la) == float(lg)
+
+
+def test_pointwise_models_device_sampler(dev):
+    """GMF / NeuMF with sampler="device": an epoch's negatives come from dr_sample_negatives_i32 (never a train item of
+    the user), every positive appears once with its label, and train() runs on it."""
+    from deeprec_amd.models._common import device_pointwise_epoch
+    from deeprec_amd.models.item_ranking.gmf import GMF
+    from deeprec_amd.models.item_ranking.neumf import NeuMF
+    rng = np.random.default_rng(3)
+    nu, ni = 60, 90
+    train, test = _toy_data(rng, nu, ni, 12)
+    for cls in (GMF, NeuMF):
+        m = quiet(cls, None, nu, ni, 0.5, 0.01, 1, 64, sampler="device")
+        quiet(m.build_network, num_neg_sample=5)
+        quiet(m.prepare_data, train, test)
+        np.random.seed(1)
+        u, i, y = (x.cpu().numpy() for x in device_pointwise_epoch(m))
+        npos = len(m.user)
+        assert len(u) == npos * 6 and int((y > 0).sum()) == npos
+        csr = train.tocsr()
+        seen = {uu: set(csr.indices[csr.indptr[uu]:csr.indptr[uu + 1]]) for uu in range(nu)}
+        neg = y == 0
+        assert all(int(it) not in seen[int(uu)] for uu, it in zip(u[neg], i[neg]))
+        assert sorted(zip(u[~neg].tolist(), i[~neg].tolist())) == sorted(zip(map(int, m.user), map(int, m.item)))
+        quiet(m.train)
+        assert 0 <= quiet(m.test)["ndcg@10"] <= 1
