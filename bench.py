@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--eval-users", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel / eval / gather extras")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying hipGraphs")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay one hipGraph per resident batch instead of launching eagerly (the eager pipelined step is "
+                         "GPU-bound: ~130 us of host time per 0.21 ms step, and graph replay measures ~8 %% slower)")
+    ap.add_argument("--no-graph", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--sharded", action="store_true",
                     help="run the row-sharded (multi-GPU) step even at --gpus 1, to price its exchange logic without a fabric")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -161,7 +164,7 @@ def main():
         def step(t):
             return eager_step(t % nb)
 
-        if not args.no_graph:
+        if args.graph and not args.no_graph:
             # the step is ~40 short launches: replay it as one hipGraph per resident batch (launch-bound otherwise)
             try:
                 eager_step(0)                       # creates helper streams / events outside capture
@@ -288,6 +291,7 @@ def sharded_eval(args, K, sh, Pt, Qt, world, rank, device, barrier):
 
 ROCPROF_NAMES = {   # live name -> kernel name in `rocprofv3 --kernel-trace --stats` output (k=128: V=4, 32 lanes/row)
     "bpr_forward_kernel": "dr::bpr_forward_kernel<4, 32>",
+    "bpr_forward_update_kernel": "dr::bpr_forward_update_1col_kernel<4, 32, 1>",
     "seg_update_kernel<item side>": "dr::seg_update_kernel<4, 32, 2, 1>",
     "seg_update_kernel<user side>": "dr::seg_update_kernel<4, 32, 1, 1>",
     "seg_long_partial_kernel": "dr::seg_long_partial_kernel<4, 32>",
@@ -298,12 +302,14 @@ SEG_CHUNK = 32      # DR_SEG_CHUNK
 
 
 def segment_census(ids):
-    """(short rows, short contributions, long rows, long contributions, partial rows) of one id list."""
+    """(short rows, short contributions, long rows, long contributions, partial rows, solo rows) of one id list;
+    short = 2..LONG_SEG contributions (the segment kernel's), solo = exactly one (the fused forward kernel's)."""
     cnt = torch.unique(ids, return_counts=True)[1]
-    short = cnt <= LONG_SEG
-    lc = cnt[~short]
+    solo = cnt == 1
+    short = (cnt <= LONG_SEG) & ~solo
+    lc = cnt[cnt > LONG_SEG]
     return (int(short.sum()), int(cnt[short].sum()), int(lc.numel()), int(lc.sum()),
-            int(((lc + SEG_CHUNK - 1) // SEG_CHUNK).sum()))
+            int(((lc + SEG_CHUNK - 1) // SEG_CHUNK).sum()), int(solo.sum()))
 
 
 def live_kernel_profile(K, run_step, n_steps):
@@ -350,8 +356,12 @@ def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step,
     # 8 B of segment metadata; a contribution costs its source row and 12 B (source index, position, coefficient)
     upd = lambda c, short: (mean([x[0 if short else 2] for x in c]) * (rows_rw * row + 8)
                             + mean([x[1 if short else 3] for x in c]) * (row + 12))
+    solo_rows = mean([x[5] for x in cQ]) + mean([x[5] for x in cP])
     alg = {
         "bpr_forward_kernel": B * (12 + 3 * row + row + 16),            # ids, 3 rows; stash row, g, loss, 2 coefficients
+        # fused forward: the same, + 3 flags per sample, + for every single-contribution row its optimizer slots
+        # read and (w, slots) written (the row itself is already counted as read)
+        "bpr_forward_update_kernel": B * (12 + 3 + 3 * row + row + 16) + solo_rows * (rows_rw - 1) * row,
         "seg_update_kernel<item side>": upd(cQ, True),
         "seg_update_kernel<user side>": upd(cP, True),
         # long segments: pass 1 reads the contributions and writes one partial row per 32; pass 2 reads the partial

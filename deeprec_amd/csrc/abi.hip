@@ -7,6 +7,28 @@ char* last_error_buf() {
     return buf;
 }
 
+// resident blocks of `kernel` on the current device (occupancy x compute units), cached per kernel and host thread
+int occupancy_blocks(const void* kernel, int block) {
+    struct Entry {
+        const void* k;
+        int blocks;
+    };
+    static thread_local Entry cache[64];
+    static thread_local int used = 0;
+    for (int e = 0; e < used; ++e)
+        if (cache[e].k == kernel) return cache[e].blocks;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu <= 0 ||
+        hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    const int blocks = per_cu * cus;
+    if (used < 64) cache[used++] = Entry{kernel, blocks};
+    return blocks;
+}
+
 // splitmix64 -> four 16-bit uniforms -> Irwin-Hall(4) ~ N(0,1).  Integer arithmetic plus one
 // exact int->float conversion and fp32 multiplies: bit-identical on host and device.
 __host__ __device__ inline float counter_normal(uint64_t seed, uint64_t idx) {

@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/deeprec_amd.h"
@@ -68,8 +69,22 @@ static inline int grid_for(int64_t work_items, int block, int items_per_block_it
     int64_t per = (int64_t)block * items_per_block_iter;
     int64_t g = (work_items + per - 1) / per;
     if (g < 1) g = 1;
-    const int64_t cap = 256 * 8;
+    static const int64_t cap = getenv("DR_GRID_CAP") ? atoll(getenv("DR_GRID_CAP")) : 256 * 8;
     return (int)(g > cap ? cap : g);
+}
+
+// Grid of a grid-stride memory-bound kernel = the number of its blocks the device holds at once (occupancy x CUs):
+// with the fixed 8-blocks-per-CU cap above, a kernel that fits only 5 or 6 blocks per CU runs 1.6 or 1.33 "waves" of
+// blocks and the partial last wave idles part of the chip (measured on the fused BPR step: 2048 blocks 184 us,
+// 1536 blocks 196 us, 1280 blocks = 5 per CU 177 us).  Cached per kernel; falls back to grid_for's cap.
+int occupancy_blocks(const void* kernel, int block);  // abi.hip
+template <typename KernelT>
+static inline int grid_resident(KernelT kernel, int64_t work_blocks, int block = 256) {
+    static const bool off = getenv("DR_GRID_CAP") != nullptr;
+    int cap = off ? 0 : occupancy_blocks(reinterpret_cast<const void*>(kernel), block);
+    if (cap <= 0) return grid_for(work_blocks, 1, 1);
+    if (work_blocks < 1) work_blocks = 1;
+    return (int)(work_blocks > cap ? cap : work_blocks);
 }
 
 // ---- vector-width selection -------------------------------------------------

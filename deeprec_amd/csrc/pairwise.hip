@@ -6,23 +6,20 @@
 // the P-side update sums (so table rows are only ever re-read in their pre-step state:
 // Q is updated first from (g, P_old), P afterwards from the stash -- see DESIGN.md).
 #include "dr_common.h"
+#include "dr_segment.h"
 
 #include <stdlib.h>
 
 namespace dr {
 
-struct SegSel {
-    uint32_t id_lo;
-    int part;
-    int pos_lo;
-};
 int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
                const int32_t* src_idx, const float* coef, int64_t n, void* plan, int64_t plan_bytes, int kind,
-               const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel, int64_t n_table);
+               const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel, int64_t n_table,
+               const float* src2 = nullptr, bool skip_single = false);
 int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, int64_t nu, int64_t ni, void* plan,
-                   int64_t plan_bytes, int k, hipStream_t st);
+                   int64_t plan_bytes, int k, hipStream_t st, bool fused);
+const unsigned char* plan_solo_flags(void* plan, int64_t n, int k);
 int check_opt(const dr_opt_params* opt, const float* slot0, const float* slot1, const char* who);
-constexpr int KIND_ACC = -1;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -104,6 +101,254 @@ __global__ __launch_bounds__(256) void bpr_forward_kernel(const float* __restric
                 for (int x = 0; x < V; ++x) d[x] = g * d[x];
                 vstore<V>(stash + b * k + c * V, d);
             }
+        }
+    }
+}
+
+// ---- BPR forward that also applies every single-contribution row (the planned step in a sparse regulariser mode) ----
+// A row that exactly one (sample, slot) of the batch touches -- at C4 every user row but a few hundred and about
+// half of the item rows -- needs no segment machinery: the sub-wave that has just read it for the dot products adds
+// its one gradient contribution, L2 and the optimizer and writes it back (solo[] flags from the plan).  Saves the
+// stash round trip, the second read of the row and of its source row, and most of the two segment launches.
+// Arithmetic = the segment kernel's for a one-contribution segment (tot = 0 + c; tot = 0 + tot; apply_row), so the
+// tables stay bit-identical to the unfused step.  stash row b = pre-step P[u_b] when the user row is solo (its item
+// rows' remaining contributions read it there, SegArgs.src2), else g * (q_i - q_j) as before.
+struct FusedTables {
+    SegArgs p, q;  // only table / slots / rows / k / kind / opt are used (apply_row)
+};
+template <int V, int LPR, int KIND>
+__global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, const int32_t* __restrict__ u,
+                                                                 const int32_t* __restrict__ i,
+                                                                 const int32_t* __restrict__ j, int64_t B,
+                                                                 const unsigned char* __restrict__ solo,
+                                                                 float* __restrict__ g_out, float* __restrict__ loss_b,
+                                                                 float* __restrict__ stash, float* __restrict__ coef2) {
+    t.p.opt = resolve(t.p.opt);
+    t.q.opt = t.p.opt;
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+    const int k = t.p.k;
+    const int cpr = k / V;
+    const int64_t nu = t.p.rows, ni = t.q.rows;
+    const float* __restrict__ P = t.p.table;
+    const float* __restrict__ Q = t.q.table;
+    const int64_t iters = (B + SPB - 1) / SPB;
+    for (int64_t it = blockIdx.x; it < iters; it += gridDim.x) {
+        const int64_t b = it * SPB + sub;
+        const bool live = b < B;
+        int64_t iu = 0, ii = 0, ij = 0;
+        bool ok = false, su = false, si = false, sj = false;
+        if (live) {
+            iu = u[b]; ii = i[b]; ij = j[b];
+            su = solo[b] != 0;
+            si = solo[B + b] != 0;
+            sj = solo[2 * B + b] != 0;
+            ok = iu >= 0 && iu < nu && ii >= 0 && ii < ni && ij >= 0 && ij < ni;
+        }
+        const bool vu = live && iu >= 0 && iu < nu;  // a solo flag implies a valid id
+        float xui = 0.0f, xuj = 0.0f;
+        float p0[V], qi0[V], qj0[V];
+        // optimizer slots of the solo rows (first column of this lane): requested together with the rows themselves,
+        // so that the sample's whole traffic is one round of loads instead of two dependent ones
+        float mu[V], vu2[V], mi[V], vi2[V], mj[V], vj2[V];
+        const int nsl = (KIND == DR_OPT_ADAM) ? 2 : kind_slots(t.p.kind);
+#pragma unroll
+        for (int x = 0; x < V; ++x) p0[x] = qi0[x] = qj0[x] = mu[x] = vu2[x] = mi[x] = vi2[x] = mj[x] = vj2[x] = 0.0f;
+        if (ok) {
+            if (lane < cpr) {
+                const int64_t ou = iu * k + lane * V, oi = ii * k + lane * V, oj = ij * k + lane * V;
+                if (su && nsl >= 1) vload<V>(mu, t.p.slot0 + ou);
+                if (su && nsl >= 2) vload<V>(vu2, t.p.slot1 + ou);
+                if (si && nsl >= 1) vload<V>(mi, t.q.slot0 + oi);
+                if (si && nsl >= 2) vload<V>(vi2, t.q.slot1 + oi);
+                if (sj && nsl >= 1) vload<V>(mj, t.q.slot0 + oj);
+                if (sj && nsl >= 2) vload<V>(vj2, t.q.slot1 + oj);
+            }
+            for (int c = lane; c < cpr; c += LPR) {
+                float pu[V], qi[V], qj[V];
+                vload<V>(pu, P + iu * k + c * V);
+                vload<V>(qi, Q + ii * k + c * V);
+                vload<V>(qj, Q + ij * k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) {
+                    xui = xui + pu[x] * qi[x];
+                    xuj = xuj + pu[x] * qj[x];
+                }
+                if (c == lane) {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) {
+                        p0[x] = pu[x];
+                        qi0[x] = qi[x];
+                        qj0[x] = qj[x];
+                    }
+                }
+            }
+        }
+        xui = subwave_sum<LPR>(xui);
+        xuj = subwave_sum<LPR>(xuj);
+        float g = 0.0f, l = 0.0f;
+        if (ok) {
+            const float s = sigmoidf_(xui - xuj);
+            l = -logf(s);
+            g = -(1.0f - s);
+        }
+        if (!live) continue;
+        if (lane == 0) {
+            g_out[b] = g;
+            loss_b[b] = l;
+            coef2[b] = g;
+            coef2[B + b] = -g;
+        }
+        const bool need_p_old = su && !(si && sj);  // some contribution of this sample goes through the segment path
+        for (int c = lane; c < cpr; c += LPR) {
+            float pu[V], qi[V], qj[V];
+            if (c == lane && ok) {
+#pragma unroll
+                for (int x = 0; x < V; ++x) {
+                    pu[x] = p0[x];
+                    qi[x] = qi0[x];
+                    qj[x] = qj0[x];
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < V; ++x) pu[x] = qi[x] = qj[x] = 0.0f;
+                if (ok || (vu && (si || sj || need_p_old))) vload<V>(pu, P + iu * k + c * V);
+                if (ok) {
+                    vload<V>(qi, Q + ii * k + c * V);
+                    vload<V>(qj, Q + ij * k + c * V);
+                }
+            }
+            // the sample's own three contributions (zero rows when the sample is invalid: g = 0, d = 0)
+            float d[V];
+#pragma unroll
+            for (int x = 0; x < V; ++x) d[x] = g * (ok ? (qi[x] - qj[x]) : 0.0f);
+            const bool pre = ok && c == lane;  // rows and slots of this column are in registers
+            if (su) {
+                float tot[V];
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = 0.0f + (0.0f + d[x]);
+                if (need_p_old) vstore<V>(stash + b * k + c * V, pu);
+                if (pre) {
+                    float w[V];
+#pragma unroll
+                    for (int x = 0; x < V; ++x) w[x] = pu[x];
+                    apply_row_loaded<V, KIND>(t.p, (uint32_t)iu, c, tot, w, mu, vu2);
+                } else {
+                    apply_row<V, KIND>(t.p, (uint32_t)iu, c, tot);
+                }
+            } else {
+                vstore<V>(stash + b * k + c * V, d);
+            }
+            if (si) {
+                float tot[V];
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = vu ? (0.0f + (0.0f + g * pu[x])) : 0.0f;
+                if (pre) apply_row_loaded<V, KIND>(t.q, (uint32_t)ii, c, tot, qi, mi, vi2);
+                else apply_row<V, KIND>(t.q, (uint32_t)ii, c, tot);
+            }
+            if (sj) {
+                float tot[V];
+                const float ng = -g;
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = vu ? (0.0f + (0.0f + ng * pu[x])) : 0.0f;
+                if (pre) apply_row_loaded<V, KIND>(t.q, (uint32_t)ij, c, tot, qj, mj, vj2);
+                else apply_row<V, KIND>(t.q, (uint32_t)ij, c, tot);
+            }
+        }
+    }
+}
+
+// The same for k == V * LPR (every lane owns exactly one vector column; k = 128, 64, 32, ...): no column loops and no
+// reload paths, every row and optimizer slot of the sample is requested in one round, and the per-id validity makes
+// the update path uniform (an invalid sample contributes zero rows to its valid solo rows, like the segment path).
+template <int V, int LPR, int KIND>
+__global__ __launch_bounds__(256) void bpr_forward_update_1col_kernel(FusedTables t, const int32_t* __restrict__ u,
+                                                                      const int32_t* __restrict__ i,
+                                                                      const int32_t* __restrict__ j, int64_t B,
+                                                                      const unsigned char* __restrict__ solo,
+                                                                      float* __restrict__ g_out,
+                                                                      float* __restrict__ loss_b,
+                                                                      float* __restrict__ stash,
+                                                                      float* __restrict__ coef2) {
+    t.p.opt = resolve(t.p.opt);
+    t.q.opt = t.p.opt;
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+    const int k = t.p.k;
+    const int64_t nu = t.p.rows, ni = t.q.rows;
+    const int nsl = (KIND == DR_OPT_ADAM) ? 2 : kind_slots(t.p.kind);
+    const int64_t iters = (B + SPB - 1) / SPB;
+    for (int64_t it = blockIdx.x; it < iters; it += gridDim.x) {
+        const int64_t b = it * SPB + sub;
+        const bool live = b < B;
+        int64_t iu = 0, ii = 0, ij = 0;
+        bool su = false, si = false, sj = false;
+        if (live) {
+            iu = u[b]; ii = i[b]; ij = j[b];
+            su = solo[b] != 0;
+            si = solo[B + b] != 0;
+            sj = solo[2 * B + b] != 0;
+        }
+        const bool vu = live && iu >= 0 && iu < nu, vi = live && ii >= 0 && ii < ni, vj = live && ij >= 0 && ij < ni;
+        const bool ok = vu && vi && vj;
+        const int64_t ou = iu * k + lane * V, oi = ii * k + lane * V, oj = ij * k + lane * V;
+        float pu[V], qi[V], qj[V], mu[V], vu2[V], mi[V], vi2[V], mj[V], vj2[V];
+#pragma unroll
+        for (int x = 0; x < V; ++x) pu[x] = qi[x] = qj[x] = mu[x] = vu2[x] = mi[x] = vi2[x] = mj[x] = vj2[x] = 0.0f;
+        if (vu) vload<V>(pu, t.p.table + ou);
+        if (vi) vload<V>(qi, t.q.table + oi);
+        if (vj) vload<V>(qj, t.q.table + oj);
+        if (su && nsl >= 1) vload<V>(mu, t.p.slot0 + ou);
+        if (su && nsl >= 2) vload<V>(vu2, t.p.slot1 + ou);
+        if (si && nsl >= 1) vload<V>(mi, t.q.slot0 + oi);
+        if (si && nsl >= 2) vload<V>(vi2, t.q.slot1 + oi);
+        if (sj && nsl >= 1) vload<V>(mj, t.q.slot0 + oj);
+        if (sj && nsl >= 2) vload<V>(vj2, t.q.slot1 + oj);
+        float xui = 0.0f, xuj = 0.0f;
+        if (ok) {
+#pragma unroll
+            for (int x = 0; x < V; ++x) {
+                xui = xui + pu[x] * qi[x];
+                xuj = xuj + pu[x] * qj[x];
+            }
+        }
+        xui = subwave_sum<LPR>(xui);
+        xuj = subwave_sum<LPR>(xuj);
+        float g = 0.0f, l = 0.0f;
+        if (ok) {
+            const float s = sigmoidf_(xui - xuj);
+            l = -logf(s);
+            g = -(1.0f - s);
+        }
+        if (!live) continue;
+        if (lane == 0) {
+            g_out[b] = g;
+            loss_b[b] = l;
+            coef2[b] = g;
+            coef2[B + b] = -g;
+        }
+        float d[V];
+#pragma unroll
+        for (int x = 0; x < V; ++x) d[x] = g * (ok ? (qi[x] - qj[x]) : 0.0f);
+        float tot[V];
+        if (si) {
+#pragma unroll
+            for (int x = 0; x < V; ++x) tot[x] = vu ? (0.0f + (0.0f + g * pu[x])) : 0.0f;
+            apply_row_loaded<V, KIND>(t.q, (uint32_t)ii, lane, tot, qi, mi, vi2);
+        }
+        if (sj) {
+            const float ng = -g;
+#pragma unroll
+            for (int x = 0; x < V; ++x) tot[x] = vu ? (0.0f + (0.0f + ng * pu[x])) : 0.0f;
+            apply_row_loaded<V, KIND>(t.q, (uint32_t)ij, lane, tot, qj, mj, vj2);
+        }
+        if (su) {
+            if (!(si && sj)) vstore<V>(stash + b * k + lane * V, pu);  // pre-step copy for the segment path
+#pragma unroll
+            for (int x = 0; x < V; ++x) tot[x] = 0.0f + (0.0f + d[x]);
+            apply_row_loaded<V, KIND>(t.p, (uint32_t)iu, lane, tot, pu, mu, vu2);
+        } else {
+            vstore<V>(stash + b * k + lane * V, d);
         }
     }
 }
@@ -393,7 +638,8 @@ static int step_layout(int64_t B, int k, int64_t stash_rows, int64_t nu, int64_t
 static int table_apply(float* T, float* s0, float* s1, int64_t rows, int k, int64_t n, const float* src,
                        int64_t src_rows, const int32_t* src_idx, const float* coef, void* plan, int64_t plan_bytes,
                        float* gdense, const dr_opt_params* opt, hipStream_t st, bool meta_ready = false,
-                       SegSel sel = SegSel{0, 0, 0}, int64_t n_table = 0) {
+                       SegSel sel = SegSel{0, 0, 0}, int64_t n_table = 0, const float* src2 = nullptr,
+                       bool skip_single = false) {
     int rc;
     if (opt->reg_mode == DR_REG_DENSE) {
         DR_HIP(hipMemsetAsync(gdense, 0, (size_t)rows * k * 4, st));
@@ -403,7 +649,7 @@ static int table_apply(float* T, float* s0, float* s1, int64_t rows, int k, int6
         return dr_dense_update_f32(T, s0, s1, gdense, rows * (int64_t)k, opt, st);
     }
     return seg_launch(T, s0, s1, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, opt->kind, opt, st, meta_ready, sel,
-                      n_table);
+                      n_table, src2, skip_single);
 }
 
 static int table_update(float* T, float* s0, float* s1, int64_t rows, int k, const int32_t* ids, int64_t n,
@@ -427,7 +673,8 @@ static int bpr_forward(const float* P, const float* Q, int64_t num_user, int64_t
     bool ok = false;
 #define DR_F(V_, L_)                                                                                                \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                          \
-        DR_LAUNCH_NAMED("bpr_forward_kernel", (bpr_forward_kernel<V_, L_>), dim3(grid_for(B, 1, 256 / L_)),         \
+        DR_LAUNCH_NAMED("bpr_forward_kernel", (bpr_forward_kernel<V_, L_>),                                         \
+                        dim3(grid_resident(bpr_forward_kernel<V_, L_>, (B + 256 / L_ - 1) / (256 / L_))),           \
                         dim3(256), 0, st, P, Q, num_user, num_item, k, u, i, j, B, g_out, loss_b, stash, coef2);    \
         ok = true;                                                                                                  \
     }
@@ -435,6 +682,44 @@ static int bpr_forward(const float* P, const float* Q, int64_t num_user, int64_t
 #undef DR_F
     DR_REQUIRE(ok, "dr_bpr_forward_f32: unsupported k=%d", k);
     DR_CHECK_LAUNCH("dr_bpr_forward_f32");
+    return DR_OK;
+}
+}  // namespace dr
+
+namespace dr {
+static int bpr_forward_update(float* P, float* Ps0, float* Ps1, int64_t num_user, float* Q, float* Qs0, float* Qs1,
+                              int64_t num_item, int32_t k, const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                              const dr_opt_params* opt, const unsigned char* solo, float* g_out, float* loss_b,
+                              float* stash, float* coef2, hipStream_t st) {
+    FusedTables t;
+    memset(&t, 0, sizeof(t));
+    t.p.table = P; t.p.slot0 = Ps0; t.p.slot1 = Ps1; t.p.rows = num_user; t.p.k = k; t.p.kind = opt->kind;
+    t.p.opt = make_optp(opt);
+    t.q = t.p;
+    t.q.table = Q; t.q.slot0 = Qs0; t.q.slot1 = Qs1; t.q.rows = num_item;
+    RowShape s = row_shape(k);
+    bool ok = false;
+#define DR_F(V_, L_)                                                                                                  \
+    if (!ok && s.V == V_ && s.LPR == L_) {                                                                            \
+        const int64_t wb_ = (B + 256 / L_ - 1) / (256 / L_);                                                           \
+        if (k == V_ * L_ && opt->kind == DR_OPT_ADAM)                                                                 \
+            DR_LAUNCH_NAMED("bpr_forward_update_kernel", (bpr_forward_update_1col_kernel<V_, L_, DR_OPT_ADAM>),       \
+                            dim3(grid_resident(bpr_forward_update_1col_kernel<V_, L_, DR_OPT_ADAM>, wb_)), dim3(256),  \
+                            0, st, t, u, i, j, B, solo, g_out, loss_b, stash, coef2);                                 \
+        else if (k == V_ * L_)                                                                                        \
+            DR_LAUNCH_NAMED("bpr_forward_update_kernel", (bpr_forward_update_1col_kernel<V_, L_, KIND_ANY>),          \
+                            dim3(grid_resident(bpr_forward_update_1col_kernel<V_, L_, KIND_ANY>, wb_)), dim3(256), 0,  \
+                            st, t, u, i, j, B, solo, g_out, loss_b, stash, coef2);                                    \
+        else                                                                                                          \
+            DR_LAUNCH_NAMED("bpr_forward_update_kernel", (bpr_forward_update_kernel<V_, L_, KIND_ANY>),               \
+                            dim3(grid_resident(bpr_forward_update_kernel<V_, L_, KIND_ANY>, wb_)), dim3(256), 0, st,   \
+                            t, u, i, j, B, solo, g_out, loss_b, stash, coef2);                                        \
+        ok = true;                                                                                                    \
+    }
+    DR_SHAPE_DISPATCH(DR_F)
+#undef DR_F
+    DR_REQUIRE(ok, "dr_bpr_step_planned_f32: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("bpr_forward_update_kernel");
     return DR_OK;
 }
 }  // namespace dr
@@ -494,13 +779,24 @@ static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_use
         DR_HIP(hipEventRecord(side->fork, st));
         DR_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
     }
+    // The planned step in a sparse regulariser mode is FUSED: the forward kernel applies every single-contribution row
+    // itself (flags in the plan), the segment kernels only see rows with two or more contributions.
+    static const bool no_fuse = getenv("DR_NO_FUSE") != nullptr;
+    const bool fused = mode != 0 && reg_mode != DR_REG_DENSE && !no_fuse;
     if (mode != 1 && B > 0) {  // enqueued first: the host then feeds the helper stream while this runs
-        rc = bpr_forward(P, Q, num_user, num_item, k, u, i, j, B, g, loss_b, stash, coefQ, st);
+        if (fused && mode == 2) {
+            const unsigned char* solo = plan_solo_flags(base + L.planA, 3 * B, k);
+            DR_REQUIRE(solo != nullptr, "dr_bpr_step_planned_f32: plan layout failed");
+            rc = bpr_forward_update(P, Pslot0, Pslot1, num_user, Q, Qslot0, Qslot1, num_item, k, u, i, j, B, opt, solo, g,
+                                    loss_b, stash, coefQ, st);
+        } else {
+            rc = bpr_forward(P, Q, num_user, num_item, k, u, i, j, B, g, loss_b, stash, coefQ, st);
+        }
         if (rc != DR_OK) return rc;
     }
     if (mode != 2) {
         if (any) {
-            rc = plan_build_bpr(u, i, j, B, num_user, num_item, base + L.planA, L.plan_bytesA, k, ps);
+            rc = plan_build_bpr(u, i, j, B, num_user, num_item, base + L.planA, L.plan_bytesA, k, ps, fused);
             if (rc != DR_OK) return rc;
             if (side) DR_HIP(hipEventRecord(side->q_ready, side->s));
         }
@@ -512,10 +808,10 @@ static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_use
         if (side) DR_HIP(hipStreamWaitEvent(st, side->q_ready, 0));
         rc = table_apply(Q, Qslot0, Qslot1, num_item, k, 3 * B, P, num_user, nullptr, coefQ, base + L.planA,
                          L.plan_bytesA, (float*)(base + L.gdenseQ), opt, st, true,
-                         SegSel{(uint32_t)num_user, 2, (int)B}, 2 * B);
+                         SegSel{(uint32_t)num_user, 2, (int)B}, 2 * B, fused ? stash : nullptr, fused);
         if (rc != DR_OK) return rc;
         rc = table_apply(P, Pslot0, Pslot1, num_user, k, 3 * B, stash, B, nullptr, nullptr, base + L.planA,
-                         L.plan_bytesA, (float*)(base + L.gdenseP), opt, st, true, SegSel{0, 1, 0}, B);
+                         L.plan_bytesA, (float*)(base + L.gdenseP), opt, st, true, SegSel{0, 1, 0}, B, nullptr, fused);
         if (rc != DR_OK) return rc;
     }
     if (loss_out) return dr_sum_f32(loss_b, B, loss_out, st);

@@ -7,6 +7,7 @@
 // to oracle/ref_ops.py:segment_sums.  The sort / scan of the plan use rocPRIM device primitives
 // (radix_sort_pairs, exclusive_scan); everything that touches table rows is hand-written.
 #include "dr_common.h"
+#include "dr_segment.h"
 
 #include <cstring>
 #include <stdlib.h>
@@ -19,7 +20,7 @@ namespace dr {
 // ---------------------------------------------------------------------------------------
 struct PlanLayout {
     int64_t hdr, keys_in, keys_out, vals_in, vals_out, flags, segidx, uniq, seg_start, temp, temp_bytes, total;
-    int64_t long_seg, long_cb, part_owner, partials, partial_rows, msrc, mcoef;
+    int64_t long_seg, long_cb, part_owner, partials, partial_rows, msrc, mcoef, solo;
 };
 
 // Segments with more than LONG_SEG contributions ("long": anything beyond the few-duplicates common case) are
@@ -72,6 +73,7 @@ static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
     L->part_owner = take(L->partial_rows * 4);
     L->msrc = take(nn * 4);
     L->mcoef = take(nn * 4);
+    L->solo = take(nn);  // one byte per ORIGINAL position: its segment has exactly one contribution (BPR plans)
     L->partials = take(L->partial_rows * (int64_t)(k_max > 0 ? k_max : 1) * 4);
     L->total = off;
     return 0;
@@ -144,18 +146,43 @@ __global__ __launch_bounds__(256) void plan_keys_bpr_kernel(const int32_t* __res
 }
 
 // source rows of the sorted contributions of a BPR batch: position p < B reads stash row p (P side), position
-// B + x reads the user row u[x mod B] (Q side: g_b * p_u)
+// B + x reads the user row u[x mod B] (Q side: g_b * p_u).
+// fused (the planned step in a sparse regulariser mode): rows whose segment holds ONE contribution are updated by
+// the forward kernel itself.  solo[p] marks those positions; a Q-side contribution of a sample whose user row is
+// solo must not read P in place (the forward kernel has already updated it) but the pre-step copy the forward kernel
+// leaves in stash row x: source index nu + x (SegArgs.src2).
 __global__ __launch_bounds__(256) void bpr_meta_kernel(const int32_t* __restrict__ sorted_pos,
-                                                       const int32_t* __restrict__ u, int64_t B, int64_t nu,
-                                                       int32_t* __restrict__ msrc) {
-    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < 3 * B; y += (int64_t)gridDim.x * 256) {
+                                                       const uint32_t* __restrict__ sk,
+                                                       const int32_t* __restrict__ u, int64_t B, int64_t nu, int64_t ni,
+                                                       int fused, int32_t* __restrict__ msrc,
+                                                       unsigned char* __restrict__ solo) {
+    const int64_t n = 3 * B;
+    const uint32_t sentinel = (uint32_t)(nu + ni);
+    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < n; y += (int64_t)gridDim.x * 256) {
         const int p = sorted_pos[y];
+        if (fused) {
+            const uint32_t key = sk[y];
+            solo[p] = (key != sentinel && (y == 0 || sk[y - 1] != key) && (y == n - 1 || sk[y + 1] != key)) ? 1 : 0;
+        }
         if (p < B) {
             msrc[y] = p;
         } else {
             const int64_t x = (p - B) % B;
             const int64_t id = u[x];
             msrc[y] = (id >= 0 && id < nu) ? (int32_t)id : -1;
+        }
+    }
+}
+
+// second pass of the fused variant (needs every solo flag): Q-side contributions of solo users read stash row x
+__global__ __launch_bounds__(256) void bpr_meta_solo_kernel(const int32_t* __restrict__ sorted_pos, int64_t B, int64_t nu,
+                                                            const unsigned char* __restrict__ solo,
+                                                            int32_t* __restrict__ msrc) {
+    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < 3 * B; y += (int64_t)gridDim.x * 256) {
+        const int p = sorted_pos[y];
+        if (p >= B) {
+            const int64_t x = (p - B) % B;
+            if (msrc[y] >= 0 && solo[x]) msrc[y] = (int32_t)(nu + x);
         }
     }
 }
@@ -196,6 +223,7 @@ constexpr int SMALL_IPT = 4, SMALL_N = 1024 * SMALL_IPT;
 template <int SMALL_T>  // 256 threads serve lists of <= 1024 keys (fewer, cheaper barriers), 1024 threads <= 4096
 __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __restrict__ keys_in, int n,
                                                               unsigned end_bit, uint32_t split_key,
+                                                              uint32_t* __restrict__ keys_out,
                                                               int32_t* __restrict__ vals_out,
                                                               int32_t* __restrict__ uniq, int32_t* __restrict__ seg_start,
                                                               int32_t* __restrict__ hdr, int32_t* __restrict__ long_seg,
@@ -226,7 +254,10 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
     for (int q = 0; q < SMALL_IPT; ++q) {
         const int e = tid * SMALL_IPT + q;
         sk[e] = key[q];
-        if (e < n) vals_out[e] = val[q];
+        if (e < n) {
+            vals_out[e] = val[q];
+            keys_out[e] = key[q];
+        }
     }
     if (tid == 0) {
         sh_nlong = 0;
@@ -280,8 +311,6 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
 // ---------------------------------------------------------------------------------------
 // segment sum (+ optimizer application)
 // ---------------------------------------------------------------------------------------
-constexpr int KIND_ACC = -1;
-
 // helper stream of the calling host thread for `main`'s device; returns `main` when it cannot be had
 hipStream_t seg_side_stream(hipStream_t main, hipEvent_t* fork, hipEvent_t* join) {
     struct Side {
@@ -314,37 +343,6 @@ hipStream_t seg_side_stream(hipStream_t main, hipEvent_t* fork, hipEvent_t* join
     return x.s;
 }
 
-struct SegSel {
-    uint32_t id_lo;
-    int part;
-    int pos_lo;
-};
-
-struct SegArgs {
-    float* table;
-    float* slot0;
-    float* slot1;
-    int64_t rows;
-    int k;
-    const float* src;
-    int64_t src_rows;
-    const int32_t* msrc;   // per SORTED contribution: source row (or -1 = skip)
-    const float* coef;     // per contribution in ORIGINAL order (read through spos), NULL = 1
-    const int32_t* spos;   // sorted position list
-    uint32_t id_lo;        // destination row = segment key - id_lo (combined two-table plans)
-    int part;              // 0: all segments, 1: those below the plan's split, 2: those at / above it
-    int pos_lo;            // coef is indexed by (position - pos_lo)
-    const int32_t* uniq;
-    const int32_t* seg_start;
-    const int32_t* hdr;       // [0] nseg, [1] n long segments
-    const int32_t* long_seg;
-    const int32_t* long_cb;
-    const int32_t* part_owner;
-    float* partials;
-    int kind;
-    OptP opt;
-};
-
 // per-contribution metadata in SORTED order, so that the segment kernels read it with plain sequential loads
 // instead of a position -> index -> row chain of dependent loads
 __global__ __launch_bounds__(256) void seg_meta_kernel(const int32_t* __restrict__ sorted_pos,
@@ -365,7 +363,6 @@ template <int V, int UNR>
 __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int c, float (&acc)[V]) {
 #pragma unroll
     for (int x = 0; x < V; ++x) acc[x] = 0.0f;
-    const float* __restrict__ src = a.src;
     for (int y = y0; y < y1; y += UNR) {
         const int n = y1 - y;  // >= 1; entries q >= n do not exist
         float v[UNR][V];
@@ -382,7 +379,7 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
         }
 #pragma unroll
         for (int q = 0; q < UNR; ++q)
-            if (si[q] >= 0) vload<V>(v[q], src + (int64_t)si[q] * a.k + c * V);
+            if (si[q] >= 0) vload<V>(v[q], seg_src_row(a, si[q]) + c * V);
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
             if (si[q] >= 0) {
@@ -391,76 +388,6 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
             }
         }
     }
-}
-
-// gradient total -> destination row (accumulate, or L2 + optimizer application)
-constexpr int KIND_ANY = -2;  // optimizer kind read from the arguments at run time
-template <int V, int KIND = KIND_ANY>
-__device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, float (&tot)[V]) {
-    const int64_t off = (int64_t)r * a.k + c * V;
-    float w[V], s0[V], s1[V];
-    if (KIND == KIND_ACC) {  // plain lookup backward (dr_scatter_add_sorted_f32)
-        vload<V>(w, a.table + off);
-#pragma unroll
-        for (int x = 0; x < V; ++x) w[x] = w[x] + tot[x];
-        vstore<V>(a.table + off, w);
-        return;
-    }
-    if (KIND == DR_OPT_ADAM) {  // the hot instantiation: no switch, all three row loads issued together
-        vload<V>(w, a.table + off);
-        vload<V>(s0, a.slot0 + off);
-        vload<V>(s1, a.slot1 + off);
-        if (a.opt.reg_mode == DR_REG_TOUCHED) {
-#pragma unroll
-            for (int x = 0; x < V; ++x) tot[x] = tot[x] + a.opt.reg * w[x];
-        }
-#pragma unroll
-        for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAM>(w[x], s0[x], s1[x], tot[x], a.opt);
-        vstore<V>(a.slot0 + off, s0);
-        vstore<V>(a.slot1 + off, s1);
-        vstore<V>(a.table + off, w);
-        return;
-    }
-    vload<V>(w, a.table + off);
-    if (a.kind == KIND_ACC) {
-#pragma unroll
-        for (int x = 0; x < V; ++x) w[x] = w[x] + tot[x];
-        vstore<V>(a.table + off, w);
-        return;
-    }
-    if (a.opt.reg_mode == DR_REG_TOUCHED) {
-#pragma unroll
-        for (int x = 0; x < V; ++x) tot[x] = tot[x] + a.opt.reg * w[x];
-    }
-    switch (a.kind) {
-        case DR_OPT_SGD:
-#pragma unroll
-            for (int x = 0; x < V; ++x) opt_apply<DR_OPT_SGD>(w[x], s0[x], s1[x], tot[x], a.opt);
-            break;
-        case DR_OPT_ADAM:
-            vload<V>(s0, a.slot0 + off);
-            vload<V>(s1, a.slot1 + off);
-#pragma unroll
-            for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAM>(w[x], s0[x], s1[x], tot[x], a.opt);
-            vstore<V>(a.slot0 + off, s0);
-            vstore<V>(a.slot1 + off, s1);
-            break;
-        case DR_OPT_ADAGRAD:
-            vload<V>(s0, a.slot0 + off);
-#pragma unroll
-            for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAGRAD>(w[x], s0[x], s1[x], tot[x], a.opt);
-            vstore<V>(a.slot0 + off, s0);
-            break;
-        default:
-            vload<V>(s0, a.slot0 + off);
-            vload<V>(s1, a.slot1 + off);
-#pragma unroll
-            for (int x = 0; x < V; ++x) opt_apply<DR_OPT_RMSPROP>(w[x], s0[x], s1[x], tot[x], a.opt);
-            vstore<V>(a.slot0 + off, s0);
-            vstore<V>(a.slot1 + off, s1);
-            break;
-    }
-    vstore<V>(a.table + off, w);
 }
 
 // short segments (<= LONG_SEG contributions, the common case): one sub-wave per segment
@@ -498,7 +425,9 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
         return g;
     };
     // sentinel segment of out-of-range ids / the other table's rows; long segments are seg_long_kernel's
-    auto live = [&](const Seg& g) { return g.go && (int64_t)g.r < a.rows && g.len <= LONG_SEG; };
+    auto live = [&](const Seg& g) {
+        return g.go && (int64_t)g.r < a.rows && g.len <= LONG_SEG && !(a.skip_single && g.len == 1);
+    };
     int s = s_lo + blockIdx.x * SPB + sub;
     Seg g0 = stage_a(s), g1 = stage_a(s + stride);
     int si0[4], sp0[4];
@@ -534,7 +463,7 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
                 float v[4][V], tot[V];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (si0[q] >= 0) vload<V>(v[q], a.src + (int64_t)si0[q] * a.k + c * V);
+                    if (si0[q] >= 0) vload<V>(v[q], seg_src_row(a, si0[q]) + c * V);
 #pragma unroll
                 for (int x = 0; x < V; ++x) tot[x] = 0.0f;
 #pragma unroll
@@ -626,6 +555,10 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
 
 template <int V, int LPR, int KIND>
 static void launch_short_k(const SegArgs& a, int grid, hipStream_t st) {
+    // grid: blocks of work; launched with at most the number of blocks the device holds at once (no partial last wave)
+    if (a.part == 2) grid = grid_resident(seg_update_kernel<V, LPR, 2, KIND>, grid);
+    else if (a.part == 1) grid = grid_resident(seg_update_kernel<V, LPR, 1, KIND>, grid);
+    else grid = grid_resident(seg_update_kernel<V, LPR, 0, KIND>, grid);
     if (a.part == 2)
         DR_LAUNCH_NAMED("seg_update_kernel<item side>", (seg_update_kernel<V, LPR, 2, KIND>), dim3(grid), dim3(256), 0, st, a);
     else if (a.part == 1)
@@ -643,7 +576,8 @@ static void launch_short(const SegArgs& a, int grid, hipStream_t st) {
 template <int V, int LPR>
 static void launch_seg(const SegArgs& a, int64_t n, hipStream_t main) {
     constexpr int SPB = 256 / LPR;
-    int grid = grid_for(n, 1, SPB);
+    int grid = (int)((n + SPB - 1) / SPB > (1 << 30) ? (1 << 30) : (n + SPB - 1) / SPB);  // capped by launch_short_k
+    if (grid < 1) grid = 1;
     // short and long segments own disjoint destination rows: the two long-segment passes run on a helper
     // stream beside the short-segment kernel (fork / join with events; also valid under graph capture)
     hipEvent_t fork = nullptr, join = nullptr;
@@ -753,11 +687,11 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
     if (n <= SMALL_N && !no_small) {
         if (n <= 256 * SMALL_IPT)
             DR_LAUNCH(plan_small_kernel<256>, dim3(1), dim3(256), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
-                      split_key, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
+                      split_key, keys_out, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
                       (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner));
         else
             DR_LAUNCH(plan_small_kernel<1024>, dim3(1), dim3(1024), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
-                      split_key, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
+                      split_key, keys_out, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
                       (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner));
         DR_CHECK_LAUNCH("plan_small_kernel");
         return DR_OK;
@@ -785,9 +719,10 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
 // One plan for both tables of a BPR batch (3B contributions: [u ; i ; j], Q keys offset by num_user) plus the
 // source-row list of the sorted contributions.  Half the launches of two separate plans.
 int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, int64_t nu, int64_t ni, void* plan,
-                   int64_t plan_bytes, int k, hipStream_t st) {
+                   int64_t plan_bytes, int k, hipStream_t st, bool fused) {
     const int64_t n = 3 * B;
     DR_REQUIRE(n < (1ll << 31) - 1 && nu + ni < (1ll << 32) - 2, "bpr plan: batch / tables too large for 32-bit keys");
+    DR_REQUIRE(!fused || nu + B < (1ll << 31) - 1, "bpr plan: num_user + B exceeds 31 bits");
     PlanLayout L;
     if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
     if (plan_bytes < L.total)
@@ -806,8 +741,14 @@ int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t
     while (end_bit < 32 && ((uint64_t)(nu + ni) >> end_bit) != 0) ++end_bit;
     int rc = plan_finish(base, L, n, end_bit, (uint32_t)nu, st);
     if (rc != DR_OK) return rc;
-    DR_LAUNCH(bpr_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int32_t*)(base + L.vals_out), u, B, nu,
-              (int32_t*)(base + L.msrc));
+    DR_LAUNCH(bpr_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int32_t*)(base + L.vals_out),
+              (const uint32_t*)(base + L.keys_out), u, B, nu, ni, fused ? 1 : 0, (int32_t*)(base + L.msrc),
+              (unsigned char*)(base + L.solo));
+    if (fused) {
+        DR_CHECK_LAUNCH("bpr_meta_kernel");
+        DR_LAUNCH(bpr_meta_solo_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int32_t*)(base + L.vals_out), B, nu,
+                  (const unsigned char*)(base + L.solo), (int32_t*)(base + L.msrc));
+    }
     DR_CHECK_LAUNCH("bpr_meta_kernel");
     return DR_OK;
 }
@@ -891,11 +832,19 @@ int seg_meta(void* plan, int64_t n, const int32_t* src_idx, int64_t src_rows, hi
 
 hipStream_t seg_side_stream(hipStream_t main, hipEvent_t* fork, hipEvent_t* join);
 
+// solo flags of a BPR plan (one byte per original position; see bpr_meta_kernel)
+const unsigned char* plan_solo_flags(void* plan, int64_t n, int k) {
+    PlanLayout L;
+    if (plan_layout(n, k, &L, last_error_buf()) != 0) return nullptr;
+    return (const unsigned char*)((char*)plan + L.solo);
+}
+
 // n: contributions the plan was built for; n_table: those of them that belong to this table (grid sizing);
 // sel: which part of a combined two-table plan this launch owns ({0,0,0} = an ordinary single-table plan)
 int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
                const int32_t* src_idx, const float* coef, int64_t n, void* plan, int64_t plan_bytes, int kind,
-               const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel, int64_t n_table) {
+               const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel, int64_t n_table, const float* src2,
+               bool skip_single) {
     PlanLayout L;
     if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
     if (plan_bytes < L.total)
@@ -910,6 +859,8 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
     a.k = k;
     a.src = src;
     a.src_rows = src_rows;
+    a.src2 = src2;
+    a.skip_single = skip_single ? 1 : 0;
     const int32_t* sorted_pos = (const int32_t*)(base + L.vals_out);
     a.spos = sorted_pos;
     a.coef = coef;
@@ -961,7 +912,7 @@ extern "C" int32_t dr_scatter_add_sorted_f32(float* gtable, int64_t rows, int32_
     if (n == 0) return DR_OK;
     DR_REQUIRE(gtable && src && plan, "dr_scatter_add_sorted_f32: NULL pointer");
     return seg_launch(gtable, nullptr, nullptr, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, KIND_ACC,
-                      nullptr, (hipStream_t)stream, false, SegSel{0, 0, 0}, 0);
+                      nullptr, (hipStream_t)stream, false, SegSel{0, 0, 0}, 0, nullptr, false);
 }
 
 extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* slot1, int64_t rows, int32_t k,
@@ -976,7 +927,7 @@ extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* s
     if (n == 0) return DR_OK;
     DR_REQUIRE(table && src && plan, "dr_sparse_row_update_f32: NULL pointer");
     return seg_launch(table, slot0, slot1, rows, k, src, src_rows, src_idx, coef, n, plan, plan_bytes, opt->kind, opt,
-                      (hipStream_t)stream, false, SegSel{0, 0, 0}, 0);
+                      (hipStream_t)stream, false, SegSel{0, 0, 0}, 0, nullptr, false);
 }
 
 extern "C" int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, const float* grad, int64_t count,

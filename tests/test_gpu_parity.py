@@ -602,6 +602,49 @@ def test_small_plan_path_equals_general_path_in_updates(dev):
     assert np.array_equal(N(a).view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", [ro.OPT_SGD, ro.OPT_ADAM, ro.OPT_ADAGRAD, ro.OPT_RMSPROP])
+@pytest.mark.parametrize("k,B,nu,ni", [(128, 1000, 5000, 300), (30, 3000, 200000, 40000), (150, 700, 50, 60),
+                                         (128, 20000, 1000000, 100000)])
+def test_planned_fused_step_equals_unplanned_step(dev, kind, k, B, nu, ni):
+    """dr_bpr_plan_f32 + dr_bpr_step_planned_f32 (single-contribution rows applied by the forward kernel, the rest by
+    the segment kernels) against dr_bpr_step_f32 (everything through the segment kernels): tables, optimizer slots
+    and loss bit-identical over three steps; duplicate-heavy and nearly duplicate-free batches, invalid ids, one-
+    workgroup and general plans."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(k + B)
+    P0 = (rng.standard_normal((nu, k)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((ni, k)) * 0.1).astype(np.float32)
+    n_slots = {ro.OPT_SGD: 0, ro.OPT_ADAM: 2, ro.OPT_ADAGRAD: 1, ro.OPT_RMSPROP: 2}[kind]
+    reg_mode = K.REG_TOUCHED if kind != ro.OPT_ADAGRAD else K.REG_NONE
+
+    def fresh():
+        P, Q = T(P0, dev), T(Q0, dev)
+        init = 0.1 if kind == ro.OPT_ADAGRAD else 0.0
+        sP = [torch.full_like(P, init) for _ in range(n_slots)] + [None, None]
+        sQ = [torch.full_like(Q, init) for _ in range(n_slots)] + [None, None]
+        return P, Q, sP, sQ, K.StepWorkspace(B, k, nu, ni, reg_mode, dev)
+    Pa, Qa, sPa, sQa, wa = fresh()
+    Pb, Qb, sPb, sQb, wb = fresh()
+    for t in range(1, 4):
+        u = rng.integers(0, nu, B).astype(np.int32)
+        i = (rng.zipf(1.2, B) % ni).astype(np.int32)
+        j = rng.integers(0, ni, B).astype(np.int32)
+        u[5], i[9], j[11] = -1, ni, -7                      # invalid ids: the sample contributes zero rows
+        j[20] = i[20]                                       # positive == negative item in one sample
+        u[30:34] = u[29]                                    # a user with five samples
+        ud, idv, jd = T(u, dev), T(i, dev), T(j, dev)
+        opt = K.opt_params(kind, lr=0.05, alpha=float(ro.adam_alpha(1e-3, 0.9, 0.999, t)), eps=1e-7, reg=0.01,
+                           reg_mode=reg_mode)
+        la = float(K.bpr_step(Pa, Qa, sPa, sQa, ud, idv, jd, opt, wa))
+        K.bpr_plan(nu, ni, k, ud, idv, jd, wb)
+        lb = float(K.bpr_step(Pb, Qb, sPb, sQb, ud, idv, jd, opt, wb, planned=True))
+        assert la == lb
+        assert torch.equal(Pa, Pb), "step %d: P differs" % t
+        assert torch.equal(Qa, Qb), "step %d: Q differs" % t
+        for x, y in zip(sPa[:n_slots] + sQa[:n_slots], sPb[:n_slots] + sQb[:n_slots]):
+            assert torch.equal(x, y), "step %d: slot differs" % t
+
+
 # ------------------------------------------------------------------ sharded step, real kernels, world 1
 def test_sharded_step_world1_equals_fused_step(dev):
     """deeprec_amd/sharding.py on the HIP kernels (one rank, so no fabric): the routed lookups, index-addressed

@@ -16,6 +16,7 @@ import os
 import sys
 
 SHORT = {
+    "bpr_forward_update_1col_kernel": "bpr_forward_update_kernel",
     "bpr_forward_kernel": "bpr_forward_kernel",
     "seg_update_kernel<4, 32, 2, 1>": "seg_update_kernel<item side>",
     "seg_update_kernel<4, 32, 1, 1>": "seg_update_kernel<user side>",

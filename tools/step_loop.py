@@ -24,10 +24,11 @@ def main():
     opt = K.opt_params(K.OPT_ADAM, lr=0.05, beta1=0.9, beta2=0.999, eps=1e-7, reg=0.1, reg_mode=K.REG_TOUCHED,
                        alpha_dev=st.alpha)
     ws = K.StepWorkspace(args.batch, args.k, args.users, args.items, K.REG_TOUCHED, dev)
-    for t in range(steps):
+    for t in range(steps):              # the planned step, as bench.py runs it (plan, then the fused forward + updates)
         u, i, j = batches[t % len(batches)]
         st.tick()
-        K.bpr_step(P, Q, sP, sQ, u, i, j, opt, ws)
+        K.bpr_plan(args.users, args.items, args.k, u, i, j, ws)
+        K.bpr_step(P, Q, sP, sQ, u, i, j, opt, ws, planned=True)
     torch.cuda.synchronize()
     print("ok", steps)
 
