@@ -22,7 +22,10 @@ def _ptr(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object
+    through several Python layers (~8 us, measured: 14 such calls were 0.12 ms of a 0.8 ms sharded step); the two C
+    calls below return the same handle in well under a microsecond."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _req(t, dtype, name, ndim=None):
