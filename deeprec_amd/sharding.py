@@ -140,11 +140,16 @@ class ShardedBpr:
         rt = BprRoute()
         # samples -> owners of their user rows
         tup, cnt = ops.route_samples(u, i, j, W, P.rows, Q.rows, self.rank << POS_BITS)
-        sc, rc = self._counts(cnt[:W], g)                          # host sync 1 (cnt[W]: invalid ids, checked below)
+        # every peer gets (samples for it, this rank's count of samples with an id out of range): a bad batch on ONE
+        # rank is then refused by ALL ranks at the same point, instead of leaving the others in the next exchange
+        pair = torch.stack((cnt[:W], cnt[W:].expand(W)), 1).contiguous()
+        s1, r1 = self._counts(pair, g)                             # host sync 1
+        sc, rc = [c[0] for c in s1], [c[0] for c in r1]
+        n_bad = [c[1] for c in r1] if self.collective else [s1[0][1]]
+        if any(n_bad):
+            raise IndexError("sharded BPR step: samples with a user / item id out of range (per rank: %s)" % n_bad)
         rt.n_s = n_s = int(sum(rc))
         n_valid = int(sum(sc))
-        if n_valid != B:
-            raise IndexError("sharded BPR step: %d of %d samples have a user / item id out of range" % (B - n_valid, B))
         smp = self._x(tup[:n_valid], n_s, rc, sc, g)               # [n_s, 4] in (source rank, batch position) order
         # item rows to fetch (distinct, per owner) and the contribution lists
         ri = ops.route_items(smp, W, self.rpo, PART_BIT)
