@@ -485,6 +485,56 @@ def bi_interaction_bwd(E, feats, gfm, s):
     return gv
 
 
+# ------------------------------------------------------------------ dense towers
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+MLP_MAX_LAYERS, MLP_MAX_DIM = 8, 256
+
+
+def _mlp_lists(x, Ws, bs, acts_kinds):
+    x = _req(x, torch.float32, "x", 2)
+    L = len(Ws)
+    if not (1 <= L <= MLP_MAX_LAYERS) or len(acts_kinds) != L or (bs is not None and len(bs) != L):
+        raise ValueError("mlp: 1..%d layers with one activation (and bias) each" % MLP_MAX_LAYERS)
+    dims = [x.shape[1]]
+    for l, W in enumerate(Ws):
+        W = _req(W, torch.float32, "W[%d]" % l, 2)
+        if W.shape[0] != dims[-1]:
+            raise ValueError("mlp: W[%d] has %d rows, the layer input has %d columns" % (l, W.shape[0], dims[-1]))
+        if bs is not None and bs[l] is not None and _req(bs[l], torch.float32, "b[%d]" % l, 1).numel() != W.shape[1]:
+            raise ValueError("mlp: b[%d] does not match W[%d]" % (l, l))
+        dims.append(W.shape[1])
+    if max(dims) > MLP_MAX_DIM:
+        raise ValueError("mlp: layer widths above %d are not supported" % MLP_MAX_DIM)
+    ptrs = lambda ts: (C.c_void_p * L)(*[t.data_ptr() if t is not None else None for t in ts])
+    return x, L, dims, (C.c_int32 * (L + 1))(*dims), (C.c_int32 * L)(*[int(a) for a in acts_kinds]), ptrs
+
+
+def mlp_forward(x, Ws, bs, acts_kinds):
+    """Whole tower in one kernel: returns acts [B, sum(dims[1:])] (every layer's output; the result is the last
+    Ws[-1].shape[1] columns)."""
+    x, L, dims, cdims, cact, ptrs = _mlp_lists(x, Ws, bs, acts_kinds)
+    acts = torch.empty((x.shape[0], sum(dims[1:])), dtype=torch.float32, device=x.device)
+    check(_abi.lib().dr_mlp_forward_f32(_ptr(x), x.shape[0], L, cdims, cact, ptrs(Ws), ptrs(bs) if bs is not None else None,
+                                        _ptr(acts), _stream()), "dr_mlp_forward_f32")
+    return acts
+
+
+def mlp_backward(x, Ws, acts_kinds, acts, gout, want_gx=True, want_gb=True):
+    """Returns (gx or None, [gW_l], [gb_l] or None) for dLoss/dh_L = gout."""
+    x, L, dims, cdims, cact, ptrs = _mlp_lists(x, Ws, None, acts_kinds)
+    gout = _req(gout, torch.float32, "gout", 2)
+    if tuple(gout.shape) != (x.shape[0], dims[-1]) or tuple(_req(acts, torch.float32, "acts", 2).shape) != (x.shape[0], sum(dims[1:])):
+        raise ValueError("mlp_backward: gout / acts do not match the tower")
+    deltas = torch.empty_like(acts)
+    gx = torch.empty_like(x) if want_gx else None
+    gW = [torch.empty_like(W) for W in Ws]
+    gb = [torch.empty(W.shape[1], dtype=torch.float32, device=x.device) for W in Ws] if want_gb else None
+    check(_abi.lib().dr_mlp_backward_f32(_ptr(x), x.shape[0], L, cdims, cact, ptrs(Ws), _ptr(acts), _ptr(gout),
+                                         _ptr(deltas), _ptr(gx), ptrs(gW), ptrs(gb) if gb is not None else None,
+                                         _stream()), "dr_mlp_backward_f32")
+    return gx, gW, gb
+
+
 # ------------------------------------------------------------------ K6
 def _csr(ptr, idx, Nu, name):
     if ptr is None:

@@ -343,6 +343,41 @@ class _BiInteraction(torch.autograd.Function):
         return None, None, None
 
 
+class _FusedMLP(torch.autograd.Function):
+    """h_{l+1} = act_l(h_l W_l + b_l) for a whole tower: dr_mlp_forward_f32 / dr_mlp_backward_f32 (three launches for
+    forward + backward instead of ~9 per layer under autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, kinds, *params):
+        L = len(kinds)
+        Ws, bs = params[:L], params[L:]
+        xc = x.contiguous()
+        acts = K.mlp_forward(xc, list(Ws), list(bs), kinds)
+        ctx.kinds = kinds
+        ctx.save_for_backward(xc, acts, *Ws)
+        return acts[:, acts.shape[1] - Ws[-1].shape[1]:].contiguous()
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, acts, *Ws = ctx.saved_tensors
+        gx, gW, gb = K.mlp_backward(x, list(Ws), ctx.kinds, acts, gout.contiguous(), want_gx=ctx.needs_input_grad[0])
+        return (gx, None) + tuple(gW) + tuple(gb)
+
+
+def fused_mlp(x, Ws, bs, kinds):
+    """Dense tower on the HIP kernels (2..8 layers, widths <= 256, B <= 1024: where a chain of library GEMM + bias +
+    activation launches is pure latency).  A single layer, a large batch, anything wider, or DR_NO_FUSED_MLP=1 uses
+    torch matmuls under autograd (measured: NFM's one hidden layer and B = 4096 are faster there)."""
+    import os
+    if (os.environ.get("DR_NO_FUSED_MLP") is not None or not (2 <= len(Ws) <= K.MLP_MAX_LAYERS) or x.shape[0] > 1024
+            or max([x.shape[1]] + [w.shape[1] for w in Ws]) > K.MLP_MAX_DIM):   # large batches: library GEMMs win
+        for W, b, kind in zip(Ws, bs, kinds):
+            x = x @ W + b
+            x = torch.relu(x) if kind == K.ACT_RELU else (torch.sigmoid(x) if kind == K.ACT_SIGMOID else x)
+        return x
+    return _FusedMLP.apply(x, tuple(int(a) for a in kinds), *Ws, *bs)
+
+
 def bi_interaction(table, feats):
     return _BiInteraction.apply(table._hook, table, feats)
 

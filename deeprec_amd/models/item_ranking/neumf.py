@@ -16,7 +16,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import GraphedStep, NegItems, TFOptimizer, device_pointwise_epoch, Table, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, NegItems, TFOptimizer, device_pointwise_epoch, fused_mlp, Table, device_of, normal_, shift_sess, to_dev
 
 
 class NeuMF(object):
@@ -69,9 +69,7 @@ class NeuMF(object):
         return self
 
     def _mlp(self, x):
-        for W, b in zip(self.kernels, self.biases):
-            x = torch.relu(x @ W + b)
-        return x
+        return fused_mlp(x, self.kernels, self.biases, [K.ACT_RELU] * len(self.kernels))
 
     def _logit(self, u, i):
         gmf = self.P.lookup(u) * self.Q.lookup(i)

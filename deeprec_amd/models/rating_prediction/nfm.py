@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from ... import kernels as K
-from .._common import GraphedStep, TFOptimizer, Table, bi_interaction, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, TFOptimizer, Table, fused_mlp, bi_interaction, device_of, normal_, shift_sess, to_dev
 
 
 class NFM():
@@ -49,7 +49,7 @@ class NFM():
 
     def _forward(self, feats, drop_mask=None):
         fm = bi_interaction(self.feature_embeddings, feats)
-        h = torch.relu(fm @ self.W1 + self.b1)
+        h = fused_mlp(fm, [self.W1], [self.b1], [K.ACT_RELU])
         if drop_mask is None:
             drop_mask = (torch.rand_like(h) < self.dropout_keep).to(h.dtype)
         h = h * drop_mask / self.dropout_keep                       # nfm.py:69, always on

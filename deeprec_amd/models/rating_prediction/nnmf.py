@@ -11,7 +11,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RatingMetrics import MAE, RMSE
-from .._common import GraphedStep, TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, TFOptimizer, Table, fused_mlp, device_of, normal_, shift_sess, to_dev
 
 
 class NNMF():
@@ -50,10 +50,7 @@ class NNMF():
 
     def _forward(self, u, i):
         x = torch.cat((self.P.lookup(u), self.Q.lookup(i), self.U.lookup(u) * self.V.lookup(i)), 1)
-        for l, (W, b) in enumerate(zip(self.kernels, self.biases)):
-            x = x @ W + b
-            if l < 4:
-                x = torch.sigmoid(x)
+        x = fused_mlp(x, self.kernels, self.biases, [K.ACT_SIGMOID] * 4 + [K.ACT_NONE])
         return x.reshape(-1)
 
     def train_op(self, batch_user, batch_item, batch_rating):

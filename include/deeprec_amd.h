@@ -285,6 +285,23 @@ int64_t dr_bucket_order_bytes(int64_t n);
 int32_t dr_bucket_order_i32(const int32_t* keys, int64_t n, int32_t nkeys, int32_t* order, int64_t* counts, void* ws,
                             int64_t ws_bytes, void* stream);
 
+/* ---- small dense towers behind the embeddings -------------------------------------------
+ * h_0 = x [B, dims[0]];  h_{l+1} = act_l(h_l W_l + b_l), W_l [dims[l], dims[l+1]] row-major, l = 0 .. L-1 (L <= 8, every
+ * width <= 256).  Replaces the tf.layers.dense chains of neumf.py:80-113, nnmf.py:60-80 and nfm.py:64-69: one kernel for
+ * the whole forward, one for the deltas, one for all weight / bias gradients (fp32 fmaf chains, k resp. batch rows in
+ * ascending order).  dims / act / W / b / gW / gb are HOST arrays (of ints resp. device pointers).
+ * acts [B, sum(dims[1..L])]: every layer's output, row-major, layer l at column offset sum(dims[1..l]); the tower's
+ * result is the last dims[L] columns.  dr_mlp_backward_f32: gout [B, dims[L]] = dLoss/dh_L; deltas = scratch shaped
+ * like acts; gx [B, dims[0]] (NULL: not wanted); gW[l] / gb[l] are overwritten (gb or gb[l] NULL: not wanted). */
+#define DR_ACT_NONE 0
+#define DR_ACT_RELU 1
+#define DR_ACT_SIGMOID 2
+int32_t dr_mlp_forward_f32(const float* x, int64_t B, int32_t L, const int32_t* dims, const int32_t* act,
+                           const float* const* W, const float* const* b, float* acts, void* stream);
+int32_t dr_mlp_backward_f32(const float* x, int64_t B, int32_t L, const int32_t* dims, const int32_t* act,
+                            const float* const* W, const float* acts, const float* gout, float* deltas, float* gx,
+                            float* const* gW, float* const* gb, void* stream);
+
 /* ---- row-sharded BPR step: routing helpers (no counterpart in the reference; SURVEY 8e, deeprec_amd/sharding.py) ----
  * A sample (u, i, j) of rank r's batch is processed by the rank that owns P[u] (u % world); that rank fetches the
  * distinct Q rows its samples need from their owners (row % world), and sends the item-side gradient rows back.

@@ -719,3 +719,42 @@ def test_sample_negatives_is_uniform_over_unseen(dev):
     assert (cnt[::2] == 0).all()
     exp = n / 32
     assert np.abs(cnt[1::2] - exp).max() < 6 * np.sqrt(exp)
+
+
+# ------------------------------------------------------------------ dense towers
+@pytest.mark.parametrize("B,dims,kinds", [(256, [128, 128, 80, 40, 20, 10], [1, 1, 1, 1, 1]),
+                                          (37, [210, 210, 50, 50, 50, 1], [2, 2, 2, 2, 0]),
+                                          (128, [128, 128], [1]), (1, [3, 256, 2], [0, 2]), (4100, [64, 16], [1])])
+def test_mlp_forward_backward(dev, B, dims, kinds):
+    """dr_mlp_forward_f32 / dr_mlp_backward_f32 against float64 torch on the CPU: outputs, input gradient and every
+    weight / bias gradient within 1e-5 relative (fp32 fmaf chains vs float64)."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(B + len(dims))
+    x = rng.standard_normal((B, dims[0])).astype(np.float32)
+    Ws = [(rng.standard_normal((dims[l], dims[l + 1])) / np.sqrt(dims[l])).astype(np.float32) for l in range(len(kinds))]
+    bs = [(rng.standard_normal(dims[l + 1]) * 0.1).astype(np.float32) for l in range(len(kinds))]
+    gout = rng.standard_normal((B, dims[-1])).astype(np.float32)
+    xd, Wd, bd = T(x, dev), [T(w, dev) for w in Ws], [T(b, dev) for b in bs]
+    acts = K.mlp_forward(xd, Wd, bd, kinds)
+    gx, gW, gb = K.mlp_backward(xd, Wd, kinds, acts, T(gout, dev))
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in Ws]
+    bt = [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in bs]
+    h, outs = xt, []
+    for W, b, kd in zip(Wt, bt, kinds):
+        h = h @ W + b
+        h = torch.relu(h) if kd == 1 else (torch.sigmoid(h) if kd == 2 else h)
+        outs.append(h)
+    (h * torch.tensor(gout, dtype=torch.float64)).sum().backward()
+    want_acts = torch.cat(outs, 1).detach().numpy()
+    tol = dict(rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(N(acts), want_acts, **tol)
+    np.testing.assert_allclose(N(gx), xt.grad.numpy(), rtol=1e-4, atol=1e-5)
+    for l in range(len(kinds)):
+        scale = max(1.0, float(np.abs(Wt[l].grad.numpy()).max()))
+        np.testing.assert_allclose(N(gW[l]), Wt[l].grad.numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg="gW%d" % l)
+        np.testing.assert_allclose(N(gb[l]), bt[l].grad.numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg="gb%d" % l)
+    # repeatable bit for bit
+    acts2 = K.mlp_forward(xd, Wd, bd, kinds)
+    gx2, gW2, _ = K.mlp_backward(xd, Wd, kinds, acts2, T(gout, dev))
+    assert torch.equal(acts, acts2) and torch.equal(gx, gx2) and all(torch.equal(a, b) for a, b in zip(gW, gW2))
