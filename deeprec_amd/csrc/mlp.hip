@@ -45,6 +45,28 @@ constexpr int MLP_KC = 64;
 constexpr int MLP_WS = MLP_MAX_DIM + 1;                      // weight chunk row stride (odd)
 constexpr int MLP_LDS_FLOATS = 2 * MLP_TB * MLP_LD + MLP_KC * MLP_WS;
 
+// Cooperative global -> LDS staging of `total` elements by 256 threads: MLP_SU loads are issued back to back into
+// registers before the first LDS store.  Written as a plain `lds[f(i)] = g[h(i)]` loop the compiler waits for every
+// load before its store, i.e. one memory round trip per element and thread: measured 7 us per 32-row chunk of the
+// weight-gradient kernel, 23 us for one 128 x 128 layer of the forward kernel.
+constexpr int MLP_SU = 16;
+template <typename Load, typename Store>
+__device__ __forceinline__ void stage(int total, int tid, Load load, Store store) {
+    for (int base = 0; base < total; base += 256 * MLP_SU) {
+        float t[MLP_SU];
+#pragma unroll
+        for (int u = 0; u < MLP_SU; ++u) {
+            const int idx = base + u * 256 + tid;
+            t[u] = idx < total ? load(idx) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < MLP_SU; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < total) store(idx, t[u]);
+        }
+    }
+}
+
 // thread layout of a layer whose per-thread dimension (output column, or input column in the delta pass) has `n`
 // entries: np = power of two >= n (>= 16), 256 / np groups, each owning rpg = 16 / groups rows of the tile
 struct Split {
@@ -87,9 +109,17 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpArgs a, const float
     const int64_t r0 = (int64_t)blockIdx.x * MLP_TB;
     const int rows = (int)((B - r0) < MLP_TB ? (B - r0) : MLP_TB);
     const int d04 = (a.dims[0] + 3) & ~3;             // columns up to the next multiple of 4 are zero (float4 reads)
-    for (int idx = tid; idx < MLP_TB * d04; idx += 256) {
-        const int r = idx / d04, c = idx - r * d04;
-        buf0[r * MLP_LD + c] = (r < rows && c < a.dims[0]) ? x[(r0 + r) * a.dims[0] + c] : 0.0f;
+    {
+        const int d0 = a.dims[0];
+        stage(MLP_TB * d04, tid,
+              [&](int idx) {
+                  const int r = idx / d04, c = idx - r * d04;
+                  return (r < rows && c < d0) ? x[(r0 + r) * d0 + c] : 0.0f;
+              },
+              [&](int idx, float v) {
+                  const int r = idx / d04, c = idx - r * d04;
+                  buf0[r * MLP_LD + c] = v;
+              });
     }
     float* in = buf0;
     float* out = buf1;
@@ -108,9 +138,15 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpArgs a, const float
             const int kc = (Kd - k0) < MLP_KC ? (Kd - k0) : MLP_KC;
             const int kc4 = (kc + 3) & ~3;
             __syncthreads();                                 // previous chunk consumed / input tile written
-            for (int idx = tid; idx < kc4 * N; idx += 256) {  // rows kc .. kc4 are zero: stale input columns times 0
-                const int k = idx / N, c = idx - k * N;
-                wch[k * S + c] = k < kc ? W[(int64_t)(k0 + k) * N + c] : 0.0f;
+            {   // rows k0 .. k0 + kc of W are one contiguous run; rows kc .. kc4 of the chunk are zero (stale input
+                // columns times 0)
+                const float* __restrict__ Wc = W + (int64_t)k0 * N;
+                const int live = kc * N;
+                stage(kc4 * N, tid, [&](int idx) { return idx < live ? Wc[idx] : 0.0f; },
+                      [&](int idx, float v) {
+                          const int k = idx / N, c = idx - k * N;
+                          wch[k * S + c] = v;
+                      });
             }
             __syncthreads();
             if (n < N) {
@@ -153,15 +189,20 @@ __global__ __launch_bounds__(256) void mlp_delta_kernel(MlpArgs a, int64_t B, co
     const int rows = (int)((B - r0) < MLP_TB ? (B - r0) : MLP_TB);
     const int NL = a.dims[a.L];
     const int NL4 = (NL + 3) & ~3;
-    for (int idx = tid; idx < MLP_TB * NL4; idx += 256) {
-        const int r = idx / NL4, c = idx - r * NL4;
-        float d = 0.0f;
-        if (r < rows && c < NL) {
-            const float y = acts[(r0 + r) * a.width + a.off[a.L - 1] + c];
-            d = gout[(r0 + r) * NL + c] * act_bwd(a.act[a.L - 1], y);
-            deltas[(r0 + r) * a.width + a.off[a.L - 1] + c] = d;
-        }
-        buf0[r * MLP_LD + c] = d;
+    {
+        const int oL = a.off[a.L - 1], kL = a.act[a.L - 1];
+        stage(MLP_TB * NL4, tid,
+              [&](int idx) {
+                  const int r = idx / NL4, c = idx - r * NL4;
+                  if (!(r < rows && c < NL)) return 0.0f;
+                  const float y = acts[(r0 + r) * a.width + oL + c];
+                  return gout[(r0 + r) * NL + c] * act_bwd(kL, y);
+              },
+              [&](int idx, float d) {
+                  const int r = idx / NL4, c = idx - r * NL4;
+                  if (r < rows && c < NL) deltas[(r0 + r) * a.width + oL + c] = d;
+                  buf0[r * MLP_LD + c] = d;
+              });
     }
     float* din = buf0;
     float* dout = buf1;
@@ -178,10 +219,15 @@ __global__ __launch_bounds__(256) void mlp_delta_kernel(MlpArgs a, int64_t B, co
             const int nc = (N - n0) < MLP_KC ? (N - n0) : MLP_KC;
             const int nc4 = (nc + 3) & ~3;
             __syncthreads();
-            for (int idx = tid; idx < Kd * nc4; idx += 256) {  // columns nc .. nc4 are zero
-                const int kk = idx / nc4, c = idx - kk * nc4;
-                wch[c * MLP_WS + kk] = c < nc ? W[(int64_t)kk * N + n0 + c] : 0.0f;   // transposed: [column][k]
-            }
+            stage(Kd * nc4, tid,                                  // columns nc .. nc4 are zero
+                  [&](int idx) {
+                      const int kk = idx / nc4, c = idx - kk * nc4;
+                      return c < nc ? W[(int64_t)kk * N + n0 + c] : 0.0f;
+                  },
+                  [&](int idx, float v) {
+                      const int kk = idx / nc4, c = idx - kk * nc4;
+                      wch[c * MLP_WS + kk] = v;                          // transposed: [column][k]
+                  });
             __syncthreads();
             if (k < Kd) {
                 switch (sp.rpg) {
@@ -246,14 +292,18 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpArgs a, const float* 
     for (int64_t rb = 0; rb < B; rb += MLP_WR) {
         const int rc = (int)((B - rb) < MLP_WR ? (B - rb) : MLP_WR);
         __syncthreads();
-        for (int idx = tid; idx < MLP_WR * MLP_WK; idx += 256) {
-            const int r = idx / MLP_WK, q = idx - r * MLP_WK;
-            hs[r][q] = (r < rc && q < kc) ? h[(rb + r) * hstride + k0 + q] : 0.0f;
-        }
-        for (int idx = tid; idx < MLP_WR * N; idx += 256) {
-            const int r = idx / N, c = idx - r * N;
-            ds[r][c] = r < rc ? dl[(rb + r) * a.width + c] : 0.0f;
-        }
+        stage(MLP_WR * MLP_WK, tid,
+              [&](int idx) {
+                  const int r = idx / MLP_WK, q = idx - r * MLP_WK;
+                  return (r < rc && q < kc) ? h[(rb + r) * hstride + k0 + q] : 0.0f;
+              },
+              [&](int idx, float v) { hs[idx / MLP_WK][idx % MLP_WK] = v; });
+        stage(MLP_WR * N, tid,
+              [&](int idx) {
+                  const int r = idx / N, c = idx - r * N;
+                  return r < rc ? dl[(rb + r) * a.width + c] : 0.0f;
+              },
+              [&](int idx, float v) { ds[idx / N][idx % N] = v; });
         __syncthreads();
         if (n < N) {
 #pragma unroll 4
