@@ -129,8 +129,8 @@ class GraphedStep:
     comes into being); call 2 copies its arguments into static buffers, captures `fn` on them (capture executes
     nothing) and replays; later calls copy and replay.  Same kernels on the same data in the same order, so results
     are bit-identical to the eager loop.  Only for steps whose host side is stateless from step to step (Adagrad /
-    RMSProp / SGD; Adam's bias correction is a per-step host scalar).  Falls back to eager for good when the shapes
-    change, capture fails, or DR_NO_GRAPH is set."""
+    RMSProp / SGD; Adam with TFOptimizer.device_alpha(), which moves the bias correction to the device).  Falls back
+    to eager for good when the shapes change, capture fails, or DR_NO_GRAPH is set."""
 
     def __init__(self, fn):
         import os
@@ -183,6 +183,7 @@ class TFOptimizer:
         self._b1p = np.float32(1)
         self._b2p = np.float32(1)
         self.slots = {}
+        self._dev = None            # K.AdamState: the bias-corrected step size lives on the device (device_alpha())
 
     def slots_for(self, t):
         key = t.data_ptr()
@@ -197,17 +198,31 @@ class TFOptimizer:
             self.slots[key] = (s + [None, None])[:2]
         return self.slots[key]
 
+    def device_alpha(self, device):
+        """Adam only: keep beta1^t, beta2^t and alpha_t on the device (dr_adam_tick_f32: the same fp32 running products
+        and the same expression as below), so that a training step has no per-step host scalar and can be replayed
+        as a hipGraph (GraphedStep).  Call before the first step."""
+        if self.kind == "adam" and self._dev is None:
+            self._dev = K.AdamState(self.lr, self.beta1, self.beta2, device)
+            if self.step_count:          # steps already taken with the host-side products: carry them over
+                self._dev.state[0] = float(self._b1p)
+                self._dev.state[1] = float(self._b2p)
+        return self
+
     def begin_step(self):
         self.step_count += 1
         self._b1p = np.float32(self._b1p * np.float32(self.beta1))
         self._b2p = np.float32(self._b2p * np.float32(self.beta2))
+        if self._dev is not None:
+            self._dev.tick()
 
     def params(self, reg, reg_mode):
         alpha = 0.0
         if self.kind == "adam":
             alpha = float(np.float32(self.lr) * np.sqrt(np.float32(1) - self._b2p) / (np.float32(1) - self._b1p))
         return K.opt_params(self.KIND[self.kind], lr=self.lr, alpha=alpha, beta1=self.beta1, beta2=self.beta2,
-                            eps=self.eps, rho=self.rho, momentum=self.momentum, reg=float(reg), reg_mode=reg_mode)
+                            eps=self.eps, rho=self.rho, momentum=self.momentum, reg=float(reg), reg_mode=reg_mode,
+                            alpha_dev=self._dev.alpha if self._dev is not None else None)
 
     def apply_dense(self, w, grad, reg=0.0):
         """Whole-tensor application; reg > 0 adds reg*w (tf l2_regularizer / l2_loss terms)."""

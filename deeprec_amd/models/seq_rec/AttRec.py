@@ -71,7 +71,8 @@ class AttRec(SeqBase):
             Wp = (torch.rand((d, d), device=dev) * 2 - 1) * lim
         self.linear_project = Wp.requires_grad_(True)
         self.optimizer = TFOptimizer("adagrad", self.learning_rate, initial_accumulator_value=0.05)
-        self._step = GraphedStep(self.train_op)
+        if self.shard is None:                       # the sharded lookups synchronise with the host (split sizes)
+            self._step = GraphedStep(self.train_op)
         return self
 
     def _seq_out(self, item_seq):

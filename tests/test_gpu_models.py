@@ -535,3 +535,41 @@ def test_pointwise_models_device_sampler(dev):
         assert sorted(zip(u[~neg].tolist(), i[~neg].tolist())) == sorted(zip(map(int, m.user), map(int, m.item)))
         quiet(m.train)
         assert 0 <= quiet(m.test)["ndcg@10"] <= 1
+
+
+def test_graphed_adam_models_equal_eager_loop(dev):
+    """BPRMF and MF train with Adam: with the bias-corrected step size on the device (TFOptimizer.device_alpha) their
+    steps replay as hipGraphs too, and leave exactly the tables the eager loop leaves."""
+    from deeprec_amd.models._common import GraphedStep
+    from deeprec_amd.models.item_ranking.bprmf import BPRMF
+    from deeprec_amd.models.rating_prediction.mf import MF
+    rng = np.random.default_rng(17)
+    t = lambda a, dt=torch.int32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    nu, ni, B = 200, 150, 512
+    P0 = (rng.standard_normal((nu, 30)) * 0.01).astype(np.float32)
+    Q0 = (rng.standard_normal((ni, 30)) * 0.01).astype(np.float32)
+    bb = [(t(rng.integers(0, nu, B)), t(rng.zipf(1.3, B) % ni), t(rng.integers(0, ni, B))) for _ in range(6)]
+    mb = [(t(rng.integers(0, nu, B)), t(rng.integers(0, ni, B)), t(rng.integers(1, 6, B), torch.float32)) for _ in range(6)]
+
+    def bprmf():
+        m = quiet(BPRMF, nu, ni)
+        m.build_network(P=P0, Q=Q0)
+        return m, [m.P, m.Q]
+
+    def mf():
+        m = quiet(MF, None, nu, ni)
+        m.build_network(P=P0, Q=Q0, B_U=np.zeros(nu, np.float32), B_I=np.zeros(ni, np.float32))
+        return m, [m.P, m.Q, m.B_U, m.B_I]
+
+    for make, batches in ((bprmf, bb), (mf, mb)):
+        a, pa = make()
+        for b in batches:
+            la = float(a.train_op(*b))
+        g, pg = make()
+        step = GraphedStep(g.train_op)
+        for b in batches:
+            lg = float(step(*b))
+        assert step.graph is not None and not step.off, "the step was not captured"
+        for x, y in zip(pa, pg):
+            assert torch.equal(x, y)
+        assert la == lg
