@@ -20,7 +20,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import GraphedStep, NegItems, TFOptimizer, device_of, normal_, sample_uniform_negatives, to_dev
+from .._common import NegItems, TFOptimizer, device_of, normal_, sample_uniform_negatives, to_dev
 
 
 class BPRMF(object):
@@ -62,8 +62,6 @@ class BPRMF(object):
         self.P = normal_((self.num_user, num_factor), 0.01, dev) if P is None else to_dev(P, torch.float32, dev)
         self.Q = normal_((self.num_item, num_factor), 0.01, dev) if Q is None else to_dev(Q, torch.float32, dev)
         self.num_factor = self.P.shape[1]
-        self.optimizer.device_alpha(dev)
-        self._step = GraphedStep(self.train_op)      # B = 1024 steps are launch-bound: one hipGraph per step
 
     def prepare_data(self, train_data, test_data):
         """bprmf.py:97-112."""
@@ -107,7 +105,7 @@ class BPRMF(object):
         for i in range(self.total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)
-            loss = self._step(u_d[s], i_d[s], j_d[s])
+            loss = self.train_op(u_d[s], i_d[s], j_d[s])
             if i % self.display_step == 0:
                 if self.verbose:
                     reg = self.reg_rate * 0.5 * float((self.P * self.P).sum() + (self.Q * self.Q).sum())

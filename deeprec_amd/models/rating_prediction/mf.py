@@ -11,7 +11,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RatingMetrics import MAE, RMSE
-from .._common import GraphedStep, TFOptimizer, device_of, normal_, shift_sess, to_dev
+from .._common import TFOptimizer, device_of, normal_, shift_sess, to_dev
 
 
 class MF():
@@ -39,8 +39,7 @@ class MF():
         self.B_U = mk(B_U, (self.num_user,))
         self.B_I = mk(B_I, (self.num_item,))
         self.num_factor = self.P.shape[1]
-        self.optimizer = TFOptimizer("adam", self.learning_rate, eps=1e-8).device_alpha(dev)
-        self._step = GraphedStep(self.train_op)
+        self.optimizer = TFOptimizer("adam", self.learning_rate, eps=1e-8)
 
     def train_op(self, batch_user, batch_item, batch_rating):
         B = batch_user.numel()
@@ -63,7 +62,7 @@ class MF():
         for i in range(total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)
-            loss = self._step(u_d[s], i_d[s], y_d[s])
+            loss = self.train_op(u_d[s], i_d[s], y_d[s])
             if i % self.display_step == 0:
                 reg = self.reg_rate * 0.5 * float(sum((t * t).sum() for t in (self.B_I, self.B_U, self.P, self.Q)))
                 print("Index: %04d; cost= %.9f" % (i + 1, float(loss.item()) + reg))

@@ -13,7 +13,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate_caser
-from .._common import GraphedStep, TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
 from ._seq_common import SeqBase
 
 
@@ -79,9 +79,7 @@ class Caser(SeqBase):
         # tf.layers.dense default kernel init would be glorot; the reference passes random_normal_initializer (sigma 1)
         self.full_w, self.full_b = dense("full_w", (fin, d), 1.0), dense("full_b", (d,), 0)
         self.fc1_dim_v, self.fc1_dim_h = n_v * d, n_h * d
-        self.optimizer = TFOptimizer("adam", self.learning_rate, eps=1e-8).device_alpha(dev)
-        if self.shard is None:                       # the sharded lookups synchronise with the host (split sizes)
-            self._step = GraphedStep(self.train_op)
+        self.optimizer = TFOptimizer("adam", self.learning_rate, eps=1e-8)
         return self
 
     def _dense_params(self):
