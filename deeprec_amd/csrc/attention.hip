@@ -1,0 +1,357 @@
+// AttRec's self-attention pooling (reference: models/seq_rec/AttRec.py:147-186) -- SURVEY 8f rank 3, row a15.
+//
+//   q = k = relu(pre)            pre = (Q[item_seq] + timing) W   [B, L, d]   (the projection GEMM stays a library GEMM)
+//   s = softmax(q q^T / sqrt(d)) over the last axis                [B, L, L]
+//   w = s with the diagonal zeroed AFTER the softmax (AttRec.py:178-180)
+//   out = mean_l (w v)[l] = (1 / L) sum_m c[m] v[m],  c[m] = sum_{l != m} s[l][m],   v = Q[item_seq]   [B, L, d]
+//
+// One workgroup per sequence: q lives in LDS (odd row stride, so the 4x4 register tiles of the L x L score matrix read
+// it without bank conflicts), the score matrix never leaves LDS except as the saved softmax the backward needs, and the
+// [B, L, L] x [B, L, d] product collapses to one weighted sum of the L value rows.  Under autograd this was ~25 library
+// launches (two batched GEMMs, softmax, mask, mean and their backward) over [B, L, d] temporaries.  fp32 VALU work on
+// L x L x d = 320 k multiply-adds per sequence: bound by the two [B, L, d] streams it reads, not by arithmetic, so no
+// MFMA here.  Deterministic: every sum has a fixed order.
+#include "dr_common.h"
+
+namespace dr {
+
+constexpr int ATT_MAX_L = 64;
+constexpr int ATT_MAX_D = 256;
+
+struct AttLayout {
+    int LP, DS, SS;       // L rounded up to 4; row stride of q (odd); row stride of the score matrix
+    int q, S, c, dc, rd, go, part, total;   // offsets in floats
+};
+
+static inline __host__ __device__ AttLayout att_layout(int L, int d) {
+    AttLayout a;
+    a.LP = (L + 3) / 4 * 4;
+    a.DS = d | 1;
+    a.SS = a.LP + 1;
+    a.q = 0;
+    a.S = a.q + a.LP * a.DS;
+    a.c = a.S + a.LP * a.SS;
+    a.dc = a.c + ATT_MAX_L;
+    a.rd = a.dc + ATT_MAX_L;
+    a.go = a.rd + ATT_MAX_L;
+    a.part = a.go + ATT_MAX_D;
+    a.total = a.part + 256;
+    return a;
+}
+
+// q[l][t] = relu(pre[b][l][t]) for l < L, 0 for the padding rows
+template <int V>
+__device__ __forceinline__ void att_stage_q(const float* __restrict__ pre_b, int L, int d, const AttLayout& A,
+                                            float* __restrict__ q) {
+    const int cpr = d / V;
+    for (int idx = threadIdx.x; idx < A.LP * cpr; idx += 256) {
+        const int l = idx / cpr, c = idx - l * cpr;
+        float r[V];
+        if (l < L) {
+            vload<V>(r, pre_b + (int64_t)l * d + c * V);
+        } else {
+#pragma unroll
+            for (int x = 0; x < V; ++x) r[x] = 0.0f;
+        }
+#pragma unroll
+        for (int x = 0; x < V; ++x) q[l * A.DS + c * V + x] = fmaxf(r[x], 0.0f);
+    }
+}
+
+// c[m] = sum over l != m of S[l][m], l ascending
+__device__ __forceinline__ void att_colsum(const float* __restrict__ S, int L, int SS, float* __restrict__ c) {
+    const int m = threadIdx.x;
+    if (m < L) {
+        float acc = 0.0f;
+        for (int l = 0; l < L; ++l)
+            if (l != m) acc += S[l * SS + m];
+        c[m] = acc;
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ v,
+                                                            int64_t B, int L, int d, float sqrt_d,
+                                                            float* __restrict__ out, float* __restrict__ s_out) {
+    extern __shared__ float lds[];
+    const AttLayout A = att_layout(L, d);
+    float* q = lds + A.q;
+    float* S = lds + A.S;
+    float* c = lds + A.c;
+    float* part = lds + A.part;
+    const int tid = threadIdx.x;
+    const int nT = A.LP / 4;
+    // the weighted row sum is split over G groups of dp threads (dp = d rounded up to a power of two)
+    int dp = 1;
+    while (dp < d) dp <<= 1;
+    const int G = 256 / dp;
+
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const float* pre_b = pre + b * L * d;
+        const float* v_b = v + b * L * d;
+        __syncthreads();   // the previous sequence's readers are done with q / S / c
+        att_stage_q<V>(pre_b, L, d, A, q);
+        __syncthreads();
+        // ---- logits: one 4x4 tile of q q^T per thread, k ascending ------------------------------------
+        if (tid < nT * nT) {
+            const int ti = tid / nT, tj = tid - ti * nT;
+            const float* qa = q + (4 * ti) * A.DS;
+            const float* qb = q + (4 * tj) * A.DS;
+            float acc[4][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = 0.0f;
+            for (int t = 0; t < d; ++t) {
+                float a[4], bb[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    a[x] = qa[x * A.DS + t];
+                    bb[x] = qb[x * A.DS + t];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) acc[x][y] = fmaf(a[x], bb[y], acc[x][y]);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) S[(4 * ti + x) * A.SS + 4 * tj + y] = acc[x][y] / sqrt_d;
+        }
+        __syncthreads();
+        // ---- softmax over each row: four lanes per row ------------------------------------------------
+        {
+            const int row = tid >> 2, sub = tid & 3;
+            const bool on = row < L;
+            float mx = -INFINITY;
+            if (on)
+                for (int m = sub; m < L; m += 4) mx = fmaxf(mx, S[row * A.SS + m]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            float sum = 0.0f;
+            if (on)
+                for (int m = sub; m < L; m += 4) {
+                    const float e = expf(S[row * A.SS + m] - mx);
+                    S[row * A.SS + m] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            if (on) {
+                float* so = s_out + (b * L + row) * L;
+                for (int m = sub; m < L; m += 4) {
+                    const float p = S[row * A.SS + m] / sum;
+                    S[row * A.SS + m] = p;
+                    so[m] = p;
+                }
+            }
+        }
+        __syncthreads();
+        att_colsum(S, L, A.SS, c);
+        __syncthreads();
+        // ---- out[col] = (sum_m c[m] v[m][col]) / L ----------------------------------------------------
+        {
+            const int col = tid & (dp - 1), g = tid / dp;
+            float acc = 0.0f;
+            if (col < d) {
+#pragma unroll 4
+                for (int m = g; m < L; m += G) acc = fmaf(c[m], v_b[(int64_t)m * d + col], acc);
+            }
+            if (G > 1) {
+                part[tid] = acc;
+                __syncthreads();
+                if (g == 0 && col < d) {
+                    for (int x = 1; x < G; ++x) acc += part[x * dp + col];
+                }
+            }
+            if (g == 0 && col < d) out[b * d + col] = acc / (float)L;
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ v,
+                                                            const float* __restrict__ s_in,
+                                                            const float* __restrict__ gout, int64_t B, int L, int d,
+                                                            float sqrt_d, float* __restrict__ dpre,
+                                                            float* __restrict__ dv) {
+    extern __shared__ float lds[];
+    const AttLayout A = att_layout(L, d);
+    float* q = lds + A.q;
+    float* S = lds + A.S;
+    float* c = lds + A.c;
+    float* dc = lds + A.dc;
+    float* rd = lds + A.rd;
+    float* go = lds + A.go;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    int dp = 1;
+    while (dp < d) dp <<= 1;
+    const int G = 256 / dp;
+    const float fL = (float)L;
+
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const float* pre_b = pre + b * L * d;
+        const float* v_b = v + b * L * d;
+        __syncthreads();
+        att_stage_q<V>(pre_b, L, d, A, q);
+        for (int idx = tid; idx < A.LP * A.LP; idx += 256) {
+            const int l = idx / A.LP, m = idx - l * A.LP;
+            S[l * A.SS + m] = (l < L && m < L) ? s_in[(b * L + l) * L + m] : 0.0f;
+        }
+        for (int t = tid; t < d; t += 256) go[t] = gout[b * d + t];
+        __syncthreads();
+        att_colsum(S, L, A.SS, c);
+        // dc[m] = <gout, v[m]> / L: one wavefront per value row, columns strided over the lanes
+        for (int m = wave; m < L; m += 4) {
+            float acc = 0.0f;
+            for (int t = lane; t < d; t += 64) acc = fmaf(go[t], v_b[(int64_t)m * d + t], acc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) dc[m] = acc / fL;
+        }
+        __syncthreads();
+        // direct part of the value gradient: dv[m] = (c[m] / L) gout
+        for (int idx = tid; idx < L * d; idx += 256) {
+            const int m = idx / d, t = idx - m * d;
+            dv[(b * L + m) * d + t] = (c[m] / fL) * go[t];
+        }
+        // rd[l] = sum over n != l of s[l][n] dc[n] (softmax backward's row term; the diagonal's upstream gradient is 0)
+        {
+            const int row = tid >> 2, sub = tid & 3;
+            float acc = 0.0f;
+            if (row < L)
+                for (int n = sub; n < L; n += 4)
+                    if (n != row) acc = fmaf(S[row * A.SS + n], dc[n], acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (row < L && sub == 0) rd[row] = acc;
+        }
+        __syncthreads();
+        // dlogits[l][m] = s[l][m] ((l != m ? dc[m] : 0) - rd[l]) / sqrt(d)
+        for (int idx = tid; idx < L * L; idx += 256) {
+            const int l = idx / L, m = idx - l * L;
+            const float up = (l != m) ? dc[m] : 0.0f;
+            S[l * A.SS + m] = (S[l * A.SS + m] * (up - rd[l])) / sqrt_d;
+        }
+        __syncthreads();
+        // query and key are the same tensor: dq = (dlogits + dlogits^T) q
+        for (int idx = tid; idx < L * L; idx += 256) {
+            const int l = idx / L, m = idx - l * L;
+            if (l <= m) {
+                const float t = S[l * A.SS + m] + S[m * A.SS + l];
+                S[l * A.SS + m] = t;
+                S[m * A.SS + l] = t;
+            }
+        }
+        __syncthreads();
+        // dpre[l][col] = relu'(pre) * sum_m G[l][m] q[m][col]: four rows per thread and pass, m ascending
+        {
+            const int col = tid & (dp - 1), g = tid / dp;
+            if (col < d) {
+                for (int l0 = 4 * g; l0 < A.LP; l0 += 4 * G) {
+                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int m = 0; m < L; ++m) {
+                        const float qv = q[m * A.DS + col];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) acc[x] = fmaf(S[(l0 + x) * A.SS + m], qv, acc[x]);
+                    }
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+                        if (l0 + x < L)
+                            dpre[(b * L + l0 + x) * d + col] = q[(l0 + x) * A.DS + col] > 0.0f ? acc[x] : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+static int att_check(const char* who, int64_t B, int32_t L, int32_t d) {
+    DR_REQUIRE(B >= 0 && L >= 1 && L <= ATT_MAX_L && d >= 1 && d <= ATT_MAX_D,
+               "%s: need B >= 0, 1 <= L <= %d, 1 <= d <= %d (got B=%lld L=%d d=%d)", who, ATT_MAX_L, ATT_MAX_D,
+               (long long)B, L, d);
+    return DR_OK;
+}
+
+// grid = the blocks the device holds at once for this (kernel, LDS size); the answer is remembered per thread
+template <typename KernelT>
+static int att_grid(KernelT kernel, int64_t B, size_t lds_bytes, int* grid) {
+    struct Seen {
+        const void* fn;
+        size_t lds;
+        int64_t cap;
+    };
+    thread_local Seen seen[8];
+    thread_local int n_seen = 0;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    int64_t cap = 0;
+    for (int x = 0; x < n_seen; ++x)
+        if (seen[x].fn == fn && seen[x].lds == lds_bytes) cap = seen[x].cap;
+    if (cap == 0) {
+        if (lds_bytes > 48 * 1024)
+            DR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        int per_cu = 0;
+        DR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes));
+        if (per_cu < 1)
+            DR_FAIL(DR_ERR_LAUNCH, "attention kernel does not fit a compute unit (%zu bytes of LDS)", lds_bytes);
+        int dev = 0, cus = 256;
+        DR_HIP(hipGetDevice(&dev));
+        DR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        cap = (int64_t)per_cu * cus;
+        seen[n_seen % 8] = Seen{fn, lds_bytes, cap};
+        if (n_seen < 8) ++n_seen;
+    }
+    *grid = (int)(B < cap ? B : cap);
+    return DR_OK;
+}
+
+}  // namespace dr
+
+using namespace dr;
+
+extern "C" int32_t dr_attn_pool_forward_f32(const float* pre, const float* v, int64_t B, int32_t L, int32_t d,
+                                            float* out, float* s, void* stream) {
+    if (int rc = att_check("dr_attn_pool_forward_f32", B, L, d)) return rc;
+    if (B == 0) return DR_OK;
+    DR_REQUIRE(pre && v && out && s, "dr_attn_pool_forward_f32: NULL pointer");
+    const bool v4 = d % 4 == 0 && ((uintptr_t)pre % 16 == 0);
+    const size_t lds = (size_t)att_layout(L, d).total * 4;
+    const float sd = (float)sqrt((double)d);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = 0;
+    if (v4) {
+        if (int rc = att_grid(attn_pool_fwd_kernel<4>, B, lds, &grid)) return rc;
+        DR_LAUNCH_NAMED("attn_pool_fwd_kernel", attn_pool_fwd_kernel<4>, dim3(grid), dim3(256), lds, st, pre, v, B,
+                        (int)L, (int)d, sd, out, s);
+    } else {
+        if (int rc = att_grid(attn_pool_fwd_kernel<1>, B, lds, &grid)) return rc;
+        DR_LAUNCH_NAMED("attn_pool_fwd_kernel", attn_pool_fwd_kernel<1>, dim3(grid), dim3(256), lds, st, pre, v, B,
+                        (int)L, (int)d, sd, out, s);
+    }
+    DR_CHECK_LAUNCH("attn_pool_fwd_kernel");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_attn_pool_backward_f32(const float* pre, const float* v, const float* s, const float* gout,
+                                             int64_t B, int32_t L, int32_t d, float* dpre, float* dv, void* stream) {
+    if (int rc = att_check("dr_attn_pool_backward_f32", B, L, d)) return rc;
+    if (B == 0) return DR_OK;
+    DR_REQUIRE(pre && v && s && gout && dpre && dv, "dr_attn_pool_backward_f32: NULL pointer");
+    const bool v4 = d % 4 == 0 && ((uintptr_t)pre % 16 == 0);
+    const size_t lds = (size_t)att_layout(L, d).total * 4;
+    const float sd = (float)sqrt((double)d);
+    hipStream_t st = (hipStream_t)stream;
+    int grid = 0;
+    if (v4) {
+        if (int rc = att_grid(attn_pool_bwd_kernel<4>, B, lds, &grid)) return rc;
+        DR_LAUNCH_NAMED("attn_pool_bwd_kernel", attn_pool_bwd_kernel<4>, dim3(grid), dim3(256), lds, st, pre, v, s, gout,
+                        B, (int)L, (int)d, sd, dpre, dv);
+    } else {
+        if (int rc = att_grid(attn_pool_bwd_kernel<1>, B, lds, &grid)) return rc;
+        DR_LAUNCH_NAMED("attn_pool_bwd_kernel", attn_pool_bwd_kernel<1>, dim3(grid), dim3(256), lds, st, pre, v, s, gout,
+                        B, (int)L, (int)d, sd, dpre, dv);
+    }
+    DR_CHECK_LAUNCH("attn_pool_bwd_kernel");
+    return DR_OK;
+}

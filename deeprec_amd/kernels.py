@@ -535,6 +535,38 @@ def mlp_backward(x, Ws, acts_kinds, acts, gout, want_gx=True, want_gb=True):
     return gx, gW, gb
 
 
+# ------------------------------------------------------------------ AttRec self-attention pooling
+ATT_MAX_L, ATT_MAX_D = 64, 256
+
+
+def attn_pool_forward(pre, v):
+    """AttRec.py:147-186 after the projection: pre, v [B, L, d] -> (out [B, d], s [B, L, L] = the unmasked softmax)."""
+    pre = _req(pre, torch.float32, "pre", 3)
+    v = _req(v, torch.float32, "v", 3)
+    if v.shape != pre.shape:
+        raise ValueError("pre and v must have the same [B, L, d] shape")
+    B, L, d = pre.shape
+    out = torch.empty((B, d), dtype=torch.float32, device=pre.device)
+    s = torch.empty((B, L, L), dtype=torch.float32, device=pre.device)
+    check(_abi.lib().dr_attn_pool_forward_f32(_ptr(pre), _ptr(v), B, L, d, _ptr(out), _ptr(s), _stream()),
+          "dr_attn_pool_forward_f32")
+    return out, s
+
+
+def attn_pool_backward(pre, v, s, gout):
+    """-> (dpre [B, L, d], dv [B, L, d]: the direct path into the values only)."""
+    pre = _req(pre, torch.float32, "pre", 3)
+    B, L, d = pre.shape
+    if _req(v, torch.float32, "v", 3).shape != pre.shape or _req(s, torch.float32, "s", 3).shape != (B, L, L) \
+            or _req(gout, torch.float32, "gout", 2).shape != (B, d):
+        raise ValueError("attn_pool_backward: v [B,L,d], s [B,L,L], gout [B,d] expected")
+    dpre = torch.empty_like(pre)
+    dv = torch.empty_like(pre)
+    check(_abi.lib().dr_attn_pool_backward_f32(_ptr(pre), _ptr(v), _ptr(s), _ptr(gout), B, L, d, _ptr(dpre), _ptr(dv),
+                                               _stream()), "dr_attn_pool_backward_f32")
+    return dpre, dv
+
+
 # ------------------------------------------------------------------ K6
 def _csr(ptr, idx, Nu, name):
     if ptr is None:

@@ -234,6 +234,11 @@ class TFOptimizer:
         s0, s1 = self.slots_for(table.w)
         pend, table.pending = table.pending, []
         if reg_mode == K.REG_DENSE:
+            if not pend:
+                # no lookup this step (AttRec's V): the gradient is reg * w alone -- no zero-filled dense gradient to
+                # write and read back (the kernel computes 0 + reg * w either way, so the result is bit-identical)
+                K.dense_update(table.w, s0, s1, None, self.params(reg, K.REG_DENSE))
+                return
             G = table.dense_grad()
             for ids, rows in pend:
                 K.scatter_add(G, ids, rows)
@@ -391,6 +396,46 @@ def fused_mlp(x, Ws, bs, kinds):
             x = torch.relu(x) if kind == K.ACT_RELU else (torch.sigmoid(x) if kind == K.ACT_SIGMOID else x)
         return x
     return _FusedMLP.apply(x, tuple(int(a) for a in kinds), *Ws, *bs)
+
+
+class _AttnSeq(torch.autograd.Function):
+    """AttRec.py:142-186 between the lookup and the distances: x = v + timing; pre = x W (library GEMM);
+    out = dr_attn_pool_forward_f32(pre, v).  Three launches forward, four backward, instead of ~25 under autograd."""
+
+    @staticmethod
+    def forward(ctx, v, timing, W):
+        B, L, d = v.shape
+        v = v.contiguous()
+        x = (v + timing).reshape(B * L, d)
+        pre = (x @ W).reshape(B, L, d)
+        out, s = K.attn_pool_forward(pre, v)
+        ctx.save_for_backward(v, x, pre, s, W)
+        ctx.mark_non_differentiable(s)
+        return out, s
+
+    @staticmethod
+    def backward(ctx, gout, _gs):
+        v, x, pre, s, W = ctx.saved_tensors
+        B, L, d = v.shape
+        dpre, dv = K.attn_pool_backward(pre, v, s, gout.contiguous())
+        dpre2 = dpre.reshape(B * L, d)
+        # dW = x^T dpre is a [d, d] result over B*L rows: as ONE GEMM the library runs it on a handful of workgroups
+        # (0.48 ms at B*L = 204 800, d = 128); split over S row blocks it is a batched GEMM plus a [S, d, d] sum
+        n = B * L
+        S = int(np.gcd(n, 64))
+        if S > 1 and n // S >= 256:
+            dW = torch.bmm(x.reshape(S, n // S, d).transpose(1, 2), dpre2.reshape(S, n // S, d)).sum(0)
+        else:
+            dW = x.t() @ dpre2
+        # the path through the projection, added onto the direct part in the GEMM's epilogue
+        dv2 = dv.reshape(n, d)
+        dv2.addmm_(dpre2, W.t())
+        return dv, None, dW
+
+
+def attn_seq(v, timing, W):
+    """(out [B, d], s [B, L, L] unmasked softmax) of AttRec's self-attention block on the HIP kernels."""
+    return _AttnSeq.apply(v, timing, W)
 
 
 def bi_interaction(table, feats):

@@ -13,7 +13,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate1
-from .._common import GraphedStep, TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import GraphedStep, TFOptimizer, Table, attn_seq, device_of, normal_, shift_sess, to_dev
 from ._seq_common import SeqBase
 
 
@@ -70,19 +70,25 @@ class AttRec(SeqBase):
             lim = math.sqrt(6.0 / (d + d))
             Wp = (torch.rand((d, d), device=dev) * 2 - 1) * lim
         self.linear_project = Wp.requires_grad_(True)
+        self._timing = None
         self.optimizer = TFOptimizer("adagrad", self.learning_rate, initial_accumulator_value=0.05)
         if self.shard is None:                       # the sharded lookups synchronise with the host (split sizes)
             self._step = GraphedStep(self.train_op)
         return self
 
-    def _seq_out(self, item_seq):
-        """AttRec.py:142-186 -> (out [B,d], weights [B,L,L])."""
+    def _seq_out(self, item_seq, want_weights=False):
+        """AttRec.py:142-186 -> (out [B,d], weights [B,L,L] or None)."""
         v = self.Q.lookup(item_seq)                                     # [B,L,d]
-        x = v + timing_signal(self.L, self.num_factor, self.device)
+        if self._timing is None:
+            self._timing = timing_signal(self.L, self.num_factor, self.device)
+        if self.L <= K.ATT_MAX_L and self.num_factor <= K.ATT_MAX_D:
+            out, s = attn_seq(v, self._timing, self.linear_project)     # dr_attn_pool_forward_f32 / _backward_f32
+            return out, (s * (1 - torch.eye(self.L, device=self.device)) if want_weights else None)
+        eye = torch.eye(self.L, device=self.device)
+        x = v + self._timing                                            # longer sequences / wider factors: library ops
         q = torch.relu(x @ self.linear_project)
         logits = q @ q.transpose(1, 2) / np.sqrt(self.num_factor)
-        w = torch.softmax(logits, -1)
-        w = w * (1 - torch.eye(self.L, device=self.device))
+        w = torch.softmax(logits, -1) * (1 - eye)
         return (w @ v).mean(1), w
 
     def _distance(self, out, user_id, item_id):
@@ -134,7 +140,7 @@ class AttRec(SeqBase):
         u = to_dev(np.asarray(user_id).reshape(-1), torch.int32, self.device)
         seq = to_dev(self.test_sequences[np.asarray(user_id).reshape(-1), :], torch.int32, self.device)
         with torch.no_grad():
-            out, w = self._seq_out(seq)
+            out, w = self._seq_out(seq, want_weights=True)
             return K.gather(self.P.w, u), out.contiguous(), K.gather(self.V.w, u), w
 
     def getItemParam(self, item_id):

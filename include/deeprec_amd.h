@@ -302,6 +302,21 @@ int32_t dr_mlp_backward_f32(const float* x, int64_t B, int32_t L, const int32_t*
                             const float* const* W, const float* acts, const float* gout, float* deltas, float* gx,
                             float* const* gW, float* const* gb, void* stream);
 
+/* ---- AttRec self-attention pooling (reference models/seq_rec/AttRec.py:147-186) ----------------
+ * pre [B, L, d] = (Q[item_seq] + timing signal) W, the pre-activation of the shared "linear_project" layer
+ * (AttRec.py:150-160; the projection itself stays a library GEMM); v [B, L, d] = Q[item_seq] (AttRec.py:142).
+ *   q = relu(pre);  s = softmax(q q^T / sqrt(d)) over the last axis (AttRec.py:174-177);
+ *   w = s with the diagonal zeroed after the softmax (AttRec.py:178-180);
+ *   out [B, d] = reduce_mean(w v, axis 1) (AttRec.py:182-186) = (sum_m c[m] v[m]) / L, c[m] = sum_{l != m} s[l][m].
+ * forward writes out and s [B, L, L] (the unmasked softmax: the backward's saved tensor; the reference's `weights`
+ * output is s with a zero diagonal).  backward: gout [B, d] = dLoss/dout -> dpre [B, L, d] (through the softmax, both
+ * uses of q and the ReLU) and dv [B, L, d] = (c[m] / L) gout, the direct path into the values only -- the caller adds
+ * dpre W^T for the path through the projection.  1 <= L <= 64, 1 <= d <= 256.  fp32, every sum in a fixed order. */
+int32_t dr_attn_pool_forward_f32(const float* pre, const float* v, int64_t B, int32_t L, int32_t d, float* out,
+                                 float* s, void* stream);
+int32_t dr_attn_pool_backward_f32(const float* pre, const float* v, const float* s, const float* gout, int64_t B,
+                                  int32_t L, int32_t d, float* dpre, float* dv, void* stream);
+
 /* ---- row-sharded BPR step: routing helpers (no counterpart in the reference; SURVEY 8e, deeprec_amd/sharding.py) ----
  * A sample (u, i, j) of rank r's batch is processed by the rank that owns P[u] (u % world); that rank fetches the
  * distinct Q rows its samples need from their owners (row % world), and sends the item-side gradient rows back.

@@ -370,6 +370,57 @@ def bi_interaction_bwd(E, feats, gFM):
 
 
 # --------------------------------------------------------------------------
+# AttRec self-attention pooling (AttRec.py:142-186, 468-510)
+# --------------------------------------------------------------------------
+def timing_signal(length, channels, min_timescale=1.0, max_timescale=1.0e4):
+    """AttRec.py:468-510 (add_timing_signal): sin / cos of position * geometric timescales, [length, channels]."""
+    position = np.arange(length, dtype=f32)
+    num_timescales = channels // 2
+    inc = np.log(float(max_timescale) / float(min_timescale)) / (float(num_timescales) - 1)
+    inv = f32(min_timescale) * np.exp(np.arange(num_timescales, dtype=f32) * f32(-inc)).astype(f32)
+    scaled = position[:, None] * inv[None, :]
+    signal = np.concatenate((np.sin(scaled), np.cos(scaled)), 1).astype(f32)
+    if channels % 2:
+        signal = np.pad(signal, ((0, 0), (0, 1)))
+    return signal
+
+
+def attn_pool_forward(pre, v, dtype=f32):
+    """AttRec.py:150-186 after the projection GEMM.  pre [B,L,d] = (Q[item_seq] + timing) W, v [B,L,d] = Q[item_seq].
+    query = key = relu(pre) (:150-160, shared "linear_project" kernel, no bias); logits = q k^T / sqrt(d) (:174);
+    weights = softmax(logits) * (1 - eye) (:177-180); out = reduce_mean(weights v, 1) (:182-186).
+    Returns (out [B,d], s [B,L,L] unmasked softmax, weights [B,L,L])."""
+    pre, v = np.asarray(pre, dtype), np.asarray(v, dtype)
+    B, L, d = pre.shape
+    q = np.maximum(pre, 0)
+    logits = np.matmul(q, q.transpose(0, 2, 1)) / dtype(np.sqrt(d))
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    s = (e / e.sum(-1, keepdims=True)).astype(dtype)
+    w = s * (1 - np.eye(L, dtype=dtype))
+    out = np.matmul(w, v).mean(1).astype(dtype)
+    return out, s, w
+
+
+def attn_pool_backward(pre, v, gout):
+    """Gradient of attn_pool_forward's `out` w.r.t. pre and (directly) v, in float64 from the chain rule:
+    c[m] = sum_{l != m} s[l,m]; dv[m] = c[m] gout / L; dc[m] = <gout, v[m]> / L; upstream of the softmax
+    dW[l,m] = dc[m] (l != m), 0 on the diagonal; dlogits = s * (dW - rowsum(s * dW)) / sqrt(d);
+    dq = (dlogits + dlogits^T) q; dpre = dq * (pre > 0).  Checked against torch autograd in tests/test_golden_cpu.py."""
+    pre, v, gout = (np.asarray(a, np.float64) for a in (pre, v, gout))
+    B, L, d = pre.shape
+    _, s, w = attn_pool_forward(pre, v, np.float64)
+    off = 1 - np.eye(L)
+    c = w.sum(1)                                               # [B, L]
+    dv = c[:, :, None] * gout[:, None, :] / L
+    dc = np.einsum("bd,bmd->bm", gout, v) / L
+    dW = dc[:, None, :] * off
+    dlog = s * (dW - (s * dW).sum(-1, keepdims=True)) / np.sqrt(d)
+    q = np.maximum(pre, 0)
+    dq = np.matmul(dlog + dlog.transpose(0, 2, 1), q)
+    return dq * (pre > 0), dv
+
+
+# --------------------------------------------------------------------------
 # K6  full-catalog scoring, masked top-K, rank-of-target
 #     (RankingMetrics.py:82-101, SeqRecMetrics.py:122-123,155,213,234)
 # --------------------------------------------------------------------------

@@ -203,3 +203,30 @@ def test_caser_convs_equal_conv2d():
     gb = torch.autograd.grad((b * coef).sum(), params)
     for x, y in zip(ga, gb):
         assert torch.allclose(x, y, rtol=1e-10, atol=1e-12)
+
+
+def test_attention_oracle_against_autograd():
+    """oracle/ref_ops.attn_pool_forward / attn_pool_backward (AttRec.py:147-186) against the literal graph under torch
+    autograd in float64, and the oracle's timing signal against the product's (AttRec.py:468-510)."""
+    import torch
+    from oracle import ref_ops as ro
+    from deeprec_amd.models.seq_rec.AttRec import timing_signal
+    rng = np.random.default_rng(5)
+    for B, L, d in ((3, 5, 16), (2, 50, 128), (4, 1, 7), (2, 7, 150)):
+        pre = rng.normal(0, 1, (B, L, d))
+        v = rng.normal(0, 1, (B, L, d))
+        gout = rng.normal(0, 1, (B, d))
+        tp = torch.tensor(pre, dtype=torch.float64, requires_grad=True)
+        tv = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+        q = torch.relu(tp)
+        w = torch.softmax(q @ q.transpose(1, 2) / np.sqrt(d), -1) * (1 - torch.eye(L, dtype=torch.float64))
+        out = (w @ tv).mean(1)
+        out.backward(torch.tensor(gout))
+        o_out, o_s, o_w = ro.attn_pool_forward(pre, v, np.float64)
+        np.testing.assert_allclose(o_out, out.detach().numpy(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(o_w, w.detach().numpy(), rtol=1e-12, atol=1e-14)
+        dpre, dv = ro.attn_pool_backward(pre, v, gout)
+        np.testing.assert_allclose(dpre, tp.grad.numpy(), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(dv, tv.grad.numpy(), rtol=1e-10, atol=1e-13)
+        if d > 2:
+            np.testing.assert_allclose(ro.timing_signal(L, d), timing_signal(L, d, "cpu")[0].numpy(), rtol=0, atol=1e-5)

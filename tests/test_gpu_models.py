@@ -575,3 +575,43 @@ def test_graphed_adam_models_equal_eager_loop(dev):
         for x, y in zip(pa, pg):
             assert torch.equal(x, y)
         assert la == lg
+
+
+def test_attrec_fused_attention_equals_library_graph(dev):
+    """AttRec.train_op with the attention block on dr_attn_pool_* (one autograd node) against the same step with the
+    block written as library ops under autograd (AttRec.py:147-186 literally): tables and the projection after three
+    Adagrad steps within 1e-5 of their scale; getUserParam's weights and output agree."""
+    from deeprec_amd import kernels as K
+    from deeprec_amd.models.seq_rec.AttRec import AttRec
+    rng = np.random.default_rng(3)
+    nu, ni, L, T_, B, d = 40, 60, 6, 3, 32, 24
+    init = {n: rng.normal(0, 0.05, (r, d)).astype(np.float32) for n, r in (("P", nu), ("V", nu), ("Q", ni), ("X", ni), ("A", ni))}
+    init["linear_project"] = rng.uniform(-0.3, 0.3, (d, d)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(torch.int32)
+    bs = [(t(rng.integers(0, nu, B)), t(rng.integers(1, ni, (B, L))), t(rng.integers(1, ni, (B, T_))),
+           t(rng.integers(1, ni, (B, T_)))) for _ in range(3)]
+
+    def run(fused):
+        old = K.ATT_MAX_L
+        K.ATT_MAX_L = old if fused else 0
+        try:
+            m = quiet(AttRec, None, nu, ni, 0.05, 0.01, 1, B)
+            quiet(m.build_network, L, T_, num_factor=d, num_neg=1, init=init)
+            losses = [float(m.train_op(*b)) for b in bs]
+            m.test_sequences = rng2.integers(1, ni, (nu, L))
+            up = m.getUserParam(np.arange(nu))
+            return m, losses, up
+        finally:
+            K.ATT_MAX_L = old
+    rng2 = np.random.default_rng(9)
+    a, la, ua = run(True)
+    rng2 = np.random.default_rng(9)
+    b, lb, ub = run(False)
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    for n in ("P", "Q", "X"):
+        wa, wb = getattr(a, n).w.cpu().numpy(), getattr(b, n).w.cpu().numpy()
+        np.testing.assert_allclose(wa, wb, rtol=1e-4, atol=1e-5 * np.abs(wb).max())
+    wa, wb = a.linear_project.detach().cpu().numpy(), b.linear_project.detach().cpu().numpy()
+    np.testing.assert_allclose(wa, wb, rtol=1e-4, atol=1e-5 * np.abs(wb).max())
+    np.testing.assert_allclose(ua[1].cpu().numpy(), ub[1].cpu().numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(ua[3].cpu().numpy(), ub[3].cpu().numpy(), rtol=1e-4, atol=1e-7)

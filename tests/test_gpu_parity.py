@@ -758,3 +758,45 @@ def test_mlp_forward_backward(dev, B, dims, kinds):
     acts2 = K.mlp_forward(xd, Wd, bd, kinds)
     gx2, gW2, _ = K.mlp_backward(xd, Wd, kinds, acts2, T(gout, dev))
     assert torch.equal(acts, acts2) and torch.equal(gx, gx2) and all(torch.equal(a, b) for a, b in zip(gW, gW2))
+
+
+# ------------------------------------------------------------------ AttRec self-attention pooling
+@pytest.mark.parametrize("B,L,d", [(3, 5, 16), (7, 50, 128), (2, 64, 256), (5, 3, 150), (4, 1, 7), (9, 50, 150),
+                                   (1100, 6, 30)])
+def test_attn_pool_forward_backward(dev, B, L, d):
+    """dr_attn_pool_forward_f32 / dr_attn_pool_backward_f32 (AttRec.py:147-186) against the oracle: output and softmax
+    within 1e-5 relative (north_star's fp32 bar), gradients within 1e-5 of their scale (float64 chain rule, itself
+    checked against autograd on CPU); two runs bit-identical."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(B * 1000 + L * 10 + d)
+    pre = rng.normal(0, 1.0, (B, L, d)).astype(np.float32)
+    v = rng.normal(0, 0.5, (B, L, d)).astype(np.float32)
+    gout = rng.normal(0, 1.0, (B, d)).astype(np.float32)
+    tp, tv, tg = T(pre, dev), T(v, dev), T(gout, dev)
+    out, s = K.attn_pool_forward(tp, tv)
+    o_out, o_s, _ = ro.attn_pool_forward(pre, v, np.float64)
+    np.testing.assert_allclose(N(s), o_s, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(N(out), o_out, rtol=1e-5, atol=1e-5 * max(np.abs(o_out).max(), 1e-30))
+    dpre, dv = K.attn_pool_backward(tp, tv, s, tg)
+    o_dpre, o_dv = ro.attn_pool_backward(pre, v, gout)
+    np.testing.assert_allclose(N(dv), o_dv, rtol=1e-5, atol=1e-5 * max(np.abs(o_dv).max(), 1e-30))
+    np.testing.assert_allclose(N(dpre), o_dpre, rtol=1e-4, atol=1e-5 * max(np.abs(o_dpre).max(), 1e-30))
+    out2, s2 = K.attn_pool_forward(tp, tv)
+    dpre2, dv2 = K.attn_pool_backward(tp, tv, s2, tg)
+    for a, b in ((out, out2), (s, s2), (dpre, dpre2), (dv, dv2)):
+        assert torch.equal(a, b)
+
+
+def test_attn_pool_rejects_bad_shapes(dev):
+    from deeprec_amd import kernels as K
+    from deeprec_amd._abi import DeepRecError
+    x = torch.zeros((2, 65, 8), device=dev)
+    with pytest.raises(DeepRecError):
+        K.attn_pool_forward(x, x)
+    y = torch.zeros((2, 4, 260), device=dev)
+    with pytest.raises(DeepRecError):
+        K.attn_pool_forward(y, y)
+    with pytest.raises(ValueError):
+        K.attn_pool_forward(torch.zeros((2, 4, 8), device=dev), torch.zeros((2, 5, 8), device=dev))
+    out, s = K.attn_pool_forward(torch.zeros((0, 4, 8), device=dev), torch.zeros((0, 4, 8), device=dev))
+    assert out.shape == (0, 8) and s.shape == (0, 4, 4)
