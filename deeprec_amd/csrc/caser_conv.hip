@@ -1,0 +1,265 @@
+// Caser's horizontal convolution block (reference: models/seq_rec/Caser.py:132-154) -- SURVEY 8f rank 3, row a16.
+//
+// For every filter height h = 1 .. L the reference runs conv2d(kernel (h, d), C filters) over e = Q[item_seq] [B, L, d],
+// ReLU, and a max over the L - h + 1 positions.  All heights share ONE filter matrix here, W [C L (L + 1) / 2, d] with
+// row C h (h - 1) / 2 + c h + r = row r of filter c of height h, so that
+//   * the products are one library GEMM per column chunk, G = e W^T (G[b, p, (h, c, r)] = <e[b, p], W[h, c, r]>);
+//   * hconv_pool_fwd_kernel turns G into the pooled output: s[t] = sum_r G[b, t + r, (h, c, r)] + bias, out = max(0,
+//     max_t s[t]), arg = the winning position (-1: the ReLU is inactive);
+//   * the backward never materialises dG: only the h rows of the winning window of each (b, h, c) carry gradient, so
+//     d e (hconv_bwd_input_kernel) and d W (hconv_bwd_filter_kernel) are sums of C L (L + 1) / 2 scaled rows per
+//     sequence -- 1 / (2 L) of the arithmetic of the two dense backward GEMMs.
+// Under autograd the strided window sums went through index_add (atomics) in the backward: 63 of 197 ms per step at
+// B = 4096, L = 50, d = 128.  All sums here have a fixed order.
+#include "dr_common.h"
+
+namespace dr {
+
+constexpr int HC_MAX_L = 64;
+constexpr int HC_MAX_D = 256;
+constexpr int HC_MAX_C = 64;
+
+__host__ __device__ static inline int64_t hc_off(int C, int h) { return (int64_t)C * h * (h - 1) / 2; }
+
+// Pooling over a column chunk of G that holds heights h0 .. h1.  One workgroup per (sequence, height, band of filters):
+// the band's [L, cb * h] slab of G (cb = as many filters as fit HC_BAND floats per row) is read coalesced into LDS (odd
+// row stride), one thread per (filter, position) sums its window's diagonal, one thread per filter takes the maximum.
+constexpr int HC_BAND = 240;
+
+__host__ __device__ static inline int hc_cb(int C, int h) {
+    int cb = HC_BAND / h;
+    return cb < 1 ? 1 : (cb > C ? C : cb);
+}
+__host__ __device__ static inline int hc_bands(int C, int h) {
+    const int cb = hc_cb(C, h);
+    return (C + cb - 1) / cb;
+}
+
+__global__ __launch_bounds__(256) void hconv_pool_fwd_kernel(const float* __restrict__ G, int64_t ldg,
+                                                             const float* __restrict__ bias, int64_t B, int L, int C,
+                                                             int h0, int h1, float* __restrict__ out,
+                                                             int32_t* __restrict__ arg) {
+    extern __shared__ float lds[];
+    int h = h0, band = blockIdx.x;
+    while (h < h1 && band >= hc_bands(C, h)) {
+        band -= hc_bands(C, h);
+        ++h;
+    }
+    const int cbmax = hc_cb(C, h);
+    const int c0 = band * cbmax;
+    const int cb = (C - c0 < cbmax) ? C - c0 : cbmax;
+    const int Wd = cb * h, Wp = Wd | 1, T = L - h + 1;
+    float* X = lds;
+    float* S2 = lds + L * Wp;      // [cb][T]
+    const int64_t col = hc_off(C, h) - hc_off(C, h0) + (int64_t)c0 * h;
+    const int tid = threadIdx.x;
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+        __syncthreads();
+        const float* src = G + b * L * ldg + col;
+        for (int idx = tid; idx < L * Wd; idx += 256) {
+            const int p = idx / Wd, x = idx - p * Wd;
+            X[p * Wp + x] = src[(int64_t)p * ldg + x];
+        }
+        __syncthreads();
+        for (int it = tid; it < cb * T; it += 256) {
+            const int c = it / T, t = it - c * T;
+            const float* x = X + t * Wp + c * h;
+            float sum = 0.0f;
+            for (int r = 0; r < h; ++r) sum += x[r * Wp + r];
+            S2[it] = sum + bias[(h - 1) * C + c0 + c];
+        }
+        __syncthreads();
+        if (tid < cb) {
+            float best = -INFINITY;
+            int bt = 0;
+            for (int t = 0; t < T; ++t) {
+                const float v = S2[tid * T + t];
+                if (v > best) {
+                    best = v;
+                    bt = t;
+                }
+            }
+            const int64_t o = b * ((int64_t)C * L) + (h - 1) * C + c0 + tid;
+            out[o] = best > 0.0f ? best : 0.0f;
+            arg[o] = best > 0.0f ? bt : -1;
+        }
+    }
+}
+
+// d e: one workgroup per sequence accumulates its [L, d] tile in LDS; column k of row p belongs to one thread
+// (k = tid % DP, p % (256 / DP) = tid / DP), contributions added in ascending (h, c, r)
+template <int DP>
+__global__ __launch_bounds__(256) void hconv_bwd_input_kernel(const float* __restrict__ gout,
+                                                              const int32_t* __restrict__ arg,
+                                                              const float* __restrict__ W, int64_t B, int L, int C,
+                                                              int d, float* __restrict__ ge) {
+    extern __shared__ float lds[];
+    constexpr int NG = 256 / DP;
+    float* acc = lds;
+    float* gs = acc + L * d;
+    int32_t* as = reinterpret_cast<int32_t*>(gs + C * L);
+    const int tid = threadIdx.x, k = tid % DP, grp = tid / DP;
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int idx = tid; idx < L * d; idx += 256) acc[idx] = 0.0f;
+        for (int idx = tid; idx < C * L; idx += 256) {
+            gs[idx] = gout[b * C * L + idx];
+            as[idx] = arg[b * C * L + idx];
+        }
+        __syncthreads();
+        if (k < d) {
+            for (int h = 1; h <= L; ++h) {
+                const float* wh = W + hc_off(C, h) * d + k;
+                for (int c = 0; c < C; ++c) {
+                    const int t0 = as[(h - 1) * C + c];
+                    const float g = gs[(h - 1) * C + c];
+                    if (t0 < 0 || g == 0.0f) continue;
+                    const float* w = wh + (int64_t)c * h * d;
+                    int r = (grp - t0) % NG;
+                    if (r < 0) r += NG;
+                    float* a = acc + (t0 + r) * d + k;
+#pragma unroll 4
+                    for (; r < h; r += NG, a += NG * d) *a = fmaf(g, w[(int64_t)r * d], *a);
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < L * d; idx += 256) ge[b * L * d + idx] = acc[idx];
+    }
+}
+
+// d W: one workgroup per (height, filter, batch chunk); the h x d partial lives in registers (thread = column k and
+// the rows r with r % (256 / DP) = tid / DP), sequences in ascending order; the chunks' partials are summed afterwards
+template <int DP>
+__global__ __launch_bounds__(256) void hconv_bwd_filter_kernel(const float* __restrict__ gout,
+                                                               const int32_t* __restrict__ arg,
+                                                               const float* __restrict__ e, int64_t B, int L, int C,
+                                                               int d, int S, float* __restrict__ partial) {
+    constexpr int NG = 256 / DP;
+    constexpr int RMAX = HC_MAX_L / NG;
+    __shared__ float gs[256];
+    __shared__ int32_t as[256];
+    const int tid = threadIdx.x, k = tid % DP, grp = tid / DP;
+    const int64_t rows = hc_off(C, L + 1);
+    // chunk-major: the workgroups resident together read the same few sequences' rows (L2), tall filters first
+    const int npairs = L * C;
+    const int s = blockIdx.x / npairs, pair = blockIdx.x % npairs;
+    const int h = L - pair / C, c = pair % C;
+    const int64_t o = (int64_t)(h - 1) * C + c;
+    const int64_t per = (B + S - 1) / S;
+    const int64_t b0 = s * per, b1 = (b0 + per < B) ? b0 + per : B;
+    float acc[RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) acc[i] = 0.0f;
+    for (int64_t bb = b0; bb < b1; bb += 256) {
+        __syncthreads();
+        if (bb + tid < b1) {
+            gs[tid] = gout[(bb + tid) * C * L + o];
+            as[tid] = arg[(bb + tid) * C * L + o];
+        }
+        __syncthreads();
+        const int n = (int)((b1 - bb < 256) ? b1 - bb : 256);
+        for (int x = 0; x < n; ++x) {
+            const int t0 = as[x];
+            const float g = gs[x];
+            if (t0 < 0 || g == 0.0f) continue;
+            const float* eb = e + ((bb + x) * L + t0) * d + k;
+#pragma unroll
+            for (int i = 0; i < RMAX; ++i) {
+                const int r = grp + i * NG;
+                if (r < h && k < d) acc[i] = fmaf(g, eb[(int64_t)r * d], acc[i]);
+            }
+        }
+    }
+    float* dst = partial + ((int64_t)s * rows + hc_off(C, h) + (int64_t)c * h) * d + k;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+        const int r = grp + i * NG;
+        if (r < h && k < d) dst[(int64_t)r * d] = acc[i];
+    }
+}
+
+static int hc_check(const char* who, int64_t B, int32_t L, int32_t C, int32_t d) {
+    DR_REQUIRE(B >= 0 && L >= 1 && L <= HC_MAX_L && C >= 1 && C <= HC_MAX_C && d >= 1 && d <= HC_MAX_D,
+               "%s: need B >= 0, 1 <= L <= %d, 1 <= C <= %d, 1 <= d <= %d (got B=%lld L=%d C=%d d=%d)", who, HC_MAX_L,
+               HC_MAX_C, HC_MAX_D, (long long)B, L, C, d);
+    return DR_OK;
+}
+
+}  // namespace dr
+
+using namespace dr;
+
+extern "C" int32_t dr_caser_hconv_pool_f32(const float* G, int64_t ldg, const float* bias, int64_t B, int32_t L,
+                                           int32_t C, int32_t h0, int32_t h1, float* out, int32_t* arg, void* stream) {
+    if (int rc = hc_check("dr_caser_hconv_pool_f32", B, L, C, 1)) return rc;
+    DR_REQUIRE(h0 >= 1 && h0 <= h1 && h1 <= L, "dr_caser_hconv_pool_f32: heights %d..%d outside 1..%d", h0, h1, L);
+    DR_REQUIRE(ldg >= hc_off(C, h1 + 1) - hc_off(C, h0), "dr_caser_hconv_pool_f32: ldg %lld < the chunk's %lld columns",
+               (long long)ldg, (long long)(hc_off(C, h1 + 1) - hc_off(C, h0)));
+    if (B == 0) return DR_OK;
+    DR_REQUIRE(G && bias && out && arg, "dr_caser_hconv_pool_f32: NULL pointer");
+    int nbands = 0;
+    size_t lds = 0;
+    for (int h = h0; h <= h1; ++h) {
+        nbands += hc_bands(C, h);
+        const int cb = hc_cb(C, h);
+        const size_t need = ((size_t)L * ((cb * h) | 1) + (size_t)cb * (L - h + 1)) * 4;
+        if (need > lds) lds = need;
+    }
+    if (lds > 48 * 1024)
+        DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hconv_pool_fwd_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int gy = (int)(B < 32768 ? B : 32768);
+    DR_LAUNCH_NAMED("hconv_pool_fwd_kernel", hconv_pool_fwd_kernel, dim3(nbands, gy), dim3(256), lds,
+                    (hipStream_t)stream, G, ldg, bias, B, (int)L, (int)C, (int)h0, (int)h1, out, arg);
+    DR_CHECK_LAUNCH("hconv_pool_fwd_kernel");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_caser_hconv_backward_input_f32(const float* gout, const int32_t* arg, const float* W, int64_t B,
+                                                     int32_t L, int32_t C, int32_t d, float* ge, void* stream) {
+    if (int rc = hc_check("dr_caser_hconv_backward_input_f32", B, L, C, d)) return rc;
+    if (B == 0) return DR_OK;
+    DR_REQUIRE(gout && arg && W && ge, "dr_caser_hconv_backward_input_f32: NULL pointer");
+    const size_t lds = ((size_t)L * d + 2 * (size_t)C * L) * 4;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(B < 2048 ? B : 2048);
+#define DR_HC(DP_)                                                                                                       \
+    do {                                                                                                                 \
+        if (lds > 48 * 1024)                                                                                             \
+            DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hconv_bwd_input_kernel<DP_>),                       \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+        DR_LAUNCH_NAMED("hconv_bwd_input_kernel", hconv_bwd_input_kernel<DP_>, dim3(grid), dim3(256), lds, st, gout, arg, \
+                        W, B, (int)L, (int)C, (int)d, ge);                                                               \
+    } while (0)
+    if (d <= 64)
+        DR_HC(64);
+    else if (d <= 128)
+        DR_HC(128);
+    else
+        DR_HC(256);
+#undef DR_HC
+    DR_CHECK_LAUNCH("hconv_bwd_input_kernel");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const int32_t* arg, const float* e, int64_t B,
+                                                      int32_t L, int32_t C, int32_t d, int32_t S, float* partial,
+                                                      void* stream) {
+    if (int rc = hc_check("dr_caser_hconv_backward_filter_f32", B, L, C, d)) return rc;
+    DR_REQUIRE(S >= 1 && S <= 64, "dr_caser_hconv_backward_filter_f32: 1 <= S <= 64 batch chunks");
+    DR_REQUIRE(gout && arg && e && partial, "dr_caser_hconv_backward_filter_f32: NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = L * C * S;
+    if (d <= 64)
+        DR_LAUNCH_NAMED("hconv_bwd_filter_kernel", hconv_bwd_filter_kernel<64>, dim3(grid), dim3(256), 0, st, gout, arg, e,
+                        B, (int)L, (int)C, (int)d, (int)S, partial);
+    else if (d <= 128)
+        DR_LAUNCH_NAMED("hconv_bwd_filter_kernel", hconv_bwd_filter_kernel<128>, dim3(grid), dim3(256), 0, st, gout, arg,
+                        e, B, (int)L, (int)C, (int)d, (int)S, partial);
+    else
+        DR_LAUNCH_NAMED("hconv_bwd_filter_kernel", hconv_bwd_filter_kernel<256>, dim3(grid), dim3(256), 0, st, gout, arg,
+                        e, B, (int)L, (int)C, (int)d, (int)S, partial);
+    DR_CHECK_LAUNCH("hconv_bwd_filter_kernel");
+    return DR_OK;
+}

@@ -567,6 +567,61 @@ def attn_pool_backward(pre, v, s, gout):
     return dpre, dv
 
 
+# ------------------------------------------------------------------ Caser horizontal convolutions
+HC_MAX_L, HC_MAX_D, HC_MAX_C = 64, 256, 64
+
+
+def hconv_rows(C, h):
+    """First row of height h's filters in the shared filter matrix (= rows of all shorter heights)."""
+    return C * h * (h - 1) // 2
+
+
+def caser_hconv_forward(e, W, bias, C, chunk_cols=4096):
+    """Caser.py:132-154: e [B, L, d], W [C L (L+1) / 2, d], bias [C L] -> (out [B, C L], arg int32 [B, C L]).
+    The products G = e W^T are library GEMMs over column chunks of whole heights (<= chunk_cols columns each)."""
+    e = _req(e, torch.float32, "e", 3)
+    W = _req(W, torch.float32, "W", 2)
+    bias = _req(bias, torch.float32, "bias", 1)
+    B, L, d = e.shape
+    if W.shape != (hconv_rows(C, L + 1), d) or bias.numel() != C * L:
+        raise ValueError("caser_hconv_forward: W must be [C L (L+1) / 2, d] and bias [C L]")
+    out = torch.empty((B, C * L), dtype=torch.float32, device=e.device)
+    arg = torch.empty((B, C * L), dtype=torch.int32, device=e.device)
+    e2 = e.reshape(B * L, d)
+    h0 = 1
+    while h0 <= L:
+        h1 = h0
+        while h1 < L and hconv_rows(C, h1 + 2) - hconv_rows(C, h0) <= chunk_cols:
+            h1 += 1
+        r0, r1 = hconv_rows(C, h0), hconv_rows(C, h1 + 1)
+        G = e2 @ W[r0:r1].t()
+        check(_abi.lib().dr_caser_hconv_pool_f32(_ptr(G), r1 - r0, _ptr(bias), B, L, C, h0, h1, _ptr(out), _ptr(arg),
+                                                 _stream()), "dr_caser_hconv_pool_f32")
+        h0 = h1 + 1
+    return out, arg
+
+
+def caser_hconv_backward(e, W, arg, gout, C):
+    """-> (ge [B, L, d], gW like W, gbias [C L]) from gout [B, C L] and the forward's arg."""
+    e = _req(e, torch.float32, "e", 3)
+    W = _req(W, torch.float32, "W", 2)
+    arg = _i32(arg, "arg")
+    gout = _req(gout, torch.float32, "gout", 2)
+    B, L, d = e.shape
+    if gout.shape != (B, C * L) or arg.shape != (B, C * L) or W.shape != (hconv_rows(C, L + 1), d):
+        raise ValueError("caser_hconv_backward: gout / arg must be [B, C L], W [C L (L+1) / 2, d]")
+    ge = torch.empty_like(e)
+    check(_abi.lib().dr_caser_hconv_backward_input_f32(_ptr(gout), _ptr(arg), _ptr(W), B, L, C, d, _ptr(ge), _stream()),
+          "dr_caser_hconv_backward_input_f32")
+    S = max(1, min(32, B // 128))      # batch chunks of the filter gradient (each one's rows stay in L2)
+    partial = torch.empty((S,) + tuple(W.shape), dtype=torch.float32, device=e.device)
+    check(_abi.lib().dr_caser_hconv_backward_filter_f32(_ptr(gout), _ptr(arg), _ptr(e), B, L, C, d, S, _ptr(partial),
+                                                        _stream()), "dr_caser_hconv_backward_filter_f32")
+    gW = partial[0] if S == 1 else partial.sum(0)
+    gbias = (gout * (arg >= 0)).sum(0)
+    return ge, gW, gbias
+
+
 # ------------------------------------------------------------------ K6
 def _csr(ptr, idx, Nu, name):
     if ptr is None:

@@ -4,9 +4,10 @@ Graph (Caser.py:39-196): tables P [U,d], V [U,d*L], Q [I,d], W [I,2d], b [I] ~ N
 (L x 1, n_v filters) and L horizontal convs (i x d, n_h filters, ReLU, max over time) on Q[item_seq];
 FC -> d (ReLU); x = concat[z, p_u]; score = <x, W_i> + b_i; loss = -mean log(sigmoid(pos)+1e-10) -
 mean log(1-sigmoid(neg)+1e-10) + reg*(l2 P,Q,V,W,b) + kernel reg; tf.train.AdamOptimizer(lr).
-The convolution block is torch (MIOpen) under autograd -- SURVEY 8(f) lists it as the dense block "next" to
-the hot path; lookups, their backward and all optimizer applications are the HIP kernels.  test() ->
-SeqRecMetrics.evaluate_caser (MFMA scoring with item bias).
+The horizontal convolutions run on the HIP kernels of csrc/caser_conv.hip (one shared filter matrix for all heights,
+library GEMMs for the products, fused window-sum / bias / ReLU / max-over-time, a sparse backward through the winning
+windows only); the vertical convolution and the FC layer are library GEMMs under autograd; lookups, their backward and
+all optimizer applications are the HIP kernels.  test() -> SeqRecMetrics.evaluate_caser (MFMA scoring with item bias).
 """
 import numpy as np
 import torch
@@ -36,6 +37,34 @@ def caser_convs(e, conv_v_w, conv_v_b, conv_h_w, conv_h_b):
         win = G.as_strided((B, L - h + 1, n_h, h), (s0, s1, h, s1 + 1))               # [b,t,c,r] -> G[b,t+r,c,r]
         outs.append(torch.relu(win.sum(3) + b).max(1)[0])                             # [B,n_h]
     return torch.cat(outs, 1)
+
+
+class _HConv(torch.autograd.Function):
+    """Caser.py:132-154 for all filter heights at once: dr_caser_hconv_pool_f32 over G = e W^T, and the backward through
+    the winning window of every (sequence, height, filter) only (dr_caser_hconv_backward_input_f32 / _filter_f32)."""
+
+    @staticmethod
+    def forward(ctx, e, W, bias, C):
+        e = e.contiguous()
+        out, arg = K.caser_hconv_forward(e, W, bias, C)
+        ctx.save_for_backward(e, W, arg)
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        e, W, arg = ctx.saved_tensors
+        ge, gW, gb = K.caser_hconv_backward(e, W, arg, gout.contiguous(), ctx.C)
+        return ge, gW, gb, None
+
+
+def caser_convs_fused(e, conv_v_w, conv_v_b, hw_cat, hb_cat, n_h):
+    """caser_convs with the horizontal block on the HIP kernels: hw_cat [n_h L (L+1) / 2, d] holds every height's
+    filters (row n_h h (h-1) / 2 + c h + r), hb_cat [n_h L] their biases in output order."""
+    B, L, d = e.shape
+    n_v = conv_v_w.shape[0]
+    out_v = torch.matmul(conv_v_w[:, 0, :, 0], e) + conv_v_b[None, :, None]
+    return torch.cat((out_v.permute(0, 2, 1).reshape(B, n_v * d), _HConv.apply(e, hw_cat, hb_cat, n_h)), 1)
 
 
 class Caser(SeqBase):
@@ -73,8 +102,21 @@ class Caser(SeqBase):
         dense = lambda n, shape, std: (to_dev(init[n], torch.float32, dev) if n in init else
                                        (normal_(shape, std, dev) if std else torch.zeros(shape, device=dev))).requires_grad_(True)
         self.conv_v_w, self.conv_v_b = dense("conv_v_w", (n_v, 1, L, 1), 1.0), dense("conv_v_b", (n_v,), 0)
-        self.conv_h_w = [dense("conv_h_w%d" % i, (n_h, 1, i, d), 1.0) for i in range(1, L + 1)]
-        self.conv_h_b = [dense("conv_h_b%d" % i, (n_h,), 0) for i in range(1, L + 1)]
+        # every height's filters in ONE parameter (row n_h h (h-1) / 2 + c h + r = row r of filter c of height h): one
+        # optimizer application instead of 2 L, and the layout the HIP kernels read; conv_h_w[i] / conv_h_b[i] are views
+        self.fused = L <= K.HC_MAX_L and d <= K.HC_MAX_D and n_h <= K.HC_MAX_C
+        rows = K.hconv_rows(n_h, L + 1)
+        hw, hb = torch.empty((rows, d), device=dev), torch.zeros(n_h * L, device=dev)
+        for i in range(1, L + 1):
+            r0 = K.hconv_rows(n_h, i)
+            hw[r0:r0 + n_h * i] = (to_dev(init["conv_h_w%d" % i], torch.float32, dev) if "conv_h_w%d" % i in init
+                                   else normal_((n_h, 1, i, d), 1.0, dev)).reshape(n_h * i, d)
+            if "conv_h_b%d" % i in init:
+                hb[(i - 1) * n_h:i * n_h] = to_dev(init["conv_h_b%d" % i], torch.float32, dev)
+        self.conv_h_wcat, self.conv_h_bcat = hw.requires_grad_(True), hb.requires_grad_(True)
+        self.conv_h_w = [self.conv_h_wcat[K.hconv_rows(n_h, i):K.hconv_rows(n_h, i + 1)].view(n_h, 1, i, d)
+                         for i in range(1, L + 1)]
+        self.conv_h_b = [self.conv_h_bcat[(i - 1) * n_h:i * n_h] for i in range(1, L + 1)]
         fin = n_v * d + n_h * L
         # tf.layers.dense default kernel init would be glorot; the reference passes random_normal_initializer (sigma 1)
         self.full_w, self.full_b = dense("full_w", (fin, d), 1.0), dense("full_b", (d,), 0)
@@ -83,11 +125,15 @@ class Caser(SeqBase):
         return self
 
     def _dense_params(self):
-        return [self.conv_v_w, self.conv_v_b, self.full_w, self.full_b] + self.conv_h_w + self.conv_h_b
+        return [self.conv_v_w, self.conv_v_b, self.full_w, self.full_b, self.conv_h_wcat, self.conv_h_bcat]
 
     def _user_emb(self, item_seq, user_id):
         """Caser.py:98-185 -> x = concat[z, p_u]  [B, 2d]."""
-        out = caser_convs(self.Q.lookup(item_seq), self.conv_v_w, self.conv_v_b, self.conv_h_w, self.conv_h_b)
+        e = self.Q.lookup(item_seq)
+        if self.fused:
+            out = caser_convs_fused(e, self.conv_v_w, self.conv_v_b, self.conv_h_wcat, self.conv_h_bcat, self.n_h)
+        else:                                   # beyond the kernels' limits (L > 64, d > 256): library ops
+            out = caser_convs(e, self.conv_v_w, self.conv_v_b, self.conv_h_w, self.conv_h_b)
         z = torch.relu(out @ self.full_w + self.full_b)
         return torch.cat((z, self.P.lookup(user_id)), 1)
 

@@ -317,6 +317,26 @@ int32_t dr_attn_pool_forward_f32(const float* pre, const float* v, int64_t B, in
 int32_t dr_attn_pool_backward_f32(const float* pre, const float* v, const float* s, const float* gout, int64_t B,
                                   int32_t L, int32_t d, float* dpre, float* dv, void* stream);
 
+/* ---- Caser horizontal convolutions (reference models/seq_rec/Caser.py:132-154) ------------------
+ * For every height h = 1 .. L: conv2d(kernel (h, d), C filters, valid) over e = Q[item_seq] [B, L, d], ReLU, max over
+ * the L - h + 1 positions; the pooled outputs are concatenated in ascending h (Caser.py:153-154): out [B, C L], column
+ * (h - 1) C + c.  All heights share one filter matrix W [C L (L + 1) / 2, d]: row C h (h - 1) / 2 + c h + r = row r of
+ * filter c of height h; bias [C L] in the order of `out`.
+ * dr_caser_hconv_pool_f32: G [B L, ldg] = e W[rows of heights h0 .. h1]^T (a library GEMM; column 0 = row
+ * C h0 (h0 - 1) / 2 of W) -> out / arg for those heights: out = max(0, max_t (sum_r G[b, t + r, (h, c, r)] + bias)),
+ * arg = the winning position t, or -1 where the ReLU is inactive.
+ * dr_caser_hconv_backward_input_f32: gout [B, C L] = dLoss/dout, arg -> ge [B, L, d] (overwritten):
+ * ge[b, arg + r] += gout[b, (h, c)] W[(h, c, r)], summed in ascending (h, c, r).
+ * dr_caser_hconv_backward_filter_f32: -> partial [S, C L (L + 1) / 2, d]: the filter gradient of batch chunk s (S
+ * chunks of ceil(B / S) sequences, ascending inside a chunk); dLoss/dW = the sum over s.  The bias gradient is the
+ * column sum of gout where arg >= 0.  1 <= L <= 64, 1 <= C <= 64, 1 <= d <= 256, 1 <= S <= 64. */
+int32_t dr_caser_hconv_pool_f32(const float* G, int64_t ldg, const float* bias, int64_t B, int32_t L, int32_t C,
+                                int32_t h0, int32_t h1, float* out, int32_t* arg, void* stream);
+int32_t dr_caser_hconv_backward_input_f32(const float* gout, const int32_t* arg, const float* W, int64_t B, int32_t L,
+                                          int32_t C, int32_t d, float* ge, void* stream);
+int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const int32_t* arg, const float* e, int64_t B, int32_t L,
+                                           int32_t C, int32_t d, int32_t S, float* partial, void* stream);
+
 /* ---- row-sharded BPR step: routing helpers (no counterpart in the reference; SURVEY 8e, deeprec_amd/sharding.py) ----
  * A sample (u, i, j) of rank r's batch is processed by the rank that owns P[u] (u % world); that rank fetches the
  * distinct Q rows its samples need from their owners (row % world), and sends the item-side gradient rows back.

@@ -421,6 +421,26 @@ def attn_pool_backward(pre, v, gout):
 
 
 # --------------------------------------------------------------------------
+# Caser horizontal convolutions (Caser.py:132-154)
+# --------------------------------------------------------------------------
+def caser_hconv_forward(e, filters, biases, dtype=f32):
+    """e [B,L,d]; filters[h-1] [C,h,d], biases[h-1] [C] for h = 1..L.  Per height: valid conv2d with kernel (h, d)
+    (:135-144) -> relu -> max over the L-h+1 positions (:149-151); concatenated in ascending h (:153-154).
+    Returns (out [B, C*L], arg [B, C*L]: winning position, -1 where the ReLU output is 0)."""
+    e = np.asarray(e, dtype)
+    B, L, d = e.shape
+    outs, args = [], []
+    for h, (w, b) in enumerate(zip(filters, biases), 1):
+        w = np.asarray(w, dtype)
+        win = np.lib.stride_tricks.sliding_window_view(e, (h, d), axis=(1, 2))[:, :, 0]      # [B, T, h, d]
+        s = np.einsum("bthd,chd->btc", win, w) + np.asarray(b, dtype)[None, None, :]
+        best = s.max(1)
+        outs.append(np.maximum(best, 0))
+        args.append(np.where(best > 0, s.argmax(1), -1))
+    return np.concatenate(outs, 1).astype(dtype), np.concatenate(args, 1).astype(np.int32)
+
+
+# --------------------------------------------------------------------------
 # K6  full-catalog scoring, masked top-K, rank-of-target
 #     (RankingMetrics.py:82-101, SeqRecMetrics.py:122-123,155,213,234)
 # --------------------------------------------------------------------------

@@ -800,3 +800,50 @@ def test_attn_pool_rejects_bad_shapes(dev):
         K.attn_pool_forward(torch.zeros((2, 4, 8), device=dev), torch.zeros((2, 5, 8), device=dev))
     out, s = K.attn_pool_forward(torch.zeros((0, 4, 8), device=dev), torch.zeros((0, 4, 8), device=dev))
     assert out.shape == (0, 8) and s.shape == (0, 4, 4)
+
+
+# ------------------------------------------------------------------ Caser horizontal convolutions
+@pytest.mark.parametrize("B,L,d,C", [(5, 5, 16, 4), (300, 7, 30, 3), (600, 50, 128, 16), (3, 64, 256, 2), (2, 1, 8, 1)])
+def test_caser_hconv_forward_backward(dev, B, L, d, C):
+    """dr_caser_hconv_pool_f32 / _backward_input_f32 / _backward_filter_f32 (Caser.py:132-154): pooled output and winning
+    positions against the oracle's literal convolution, gradients against float64 autograd through the library form
+    (caser_convs, itself checked against conv2d on CPU); two runs bit-identical."""
+    from deeprec_amd import kernels as K
+    from deeprec_amd.models.seq_rec.Caser import caser_convs
+    rng = np.random.default_rng(B + 7 * L + d)
+    e = rng.normal(0, 0.5, (B, L, d)).astype(np.float32)
+    filt = [rng.normal(0, 1.0 / np.sqrt(h * d), (C, h, d)).astype(np.float32) for h in range(1, L + 1)]
+    bias = [rng.normal(-0.2, 0.2, C).astype(np.float32) for _ in range(L)]
+    R = rng.normal(0, 1, (B, C * L)).astype(np.float32)
+    Wcat = np.concatenate([f.reshape(-1, d) for f in filt], 0)
+    te, tW, tb, tR = T(e, dev), T(Wcat, dev), T(np.concatenate(bias), dev), T(R, dev)
+    out, arg = K.caser_hconv_forward(te, tW, tb, C, chunk_cols=max(C * L, 600))
+    o_out, o_arg = ro.caser_hconv_forward(e, filt, bias, np.float64)
+    scale = max(np.abs(o_out).max(), 1e-30)
+    np.testing.assert_allclose(N(out), o_out, rtol=1e-5, atol=1e-5 * scale)
+    clear = np.abs(o_out) > 1e-4 * scale                  # a pre-activation within rounding of 0 may flip the ReLU
+    assert np.array_equal(N(arg)[clear] >= 0, o_arg[clear] >= 0)
+    assert (N(arg) == o_arg).mean() > 0.999               # near-ties between two positions may pick the other one
+    ge, gW, gb = K.caser_hconv_backward(te, tW, arg, tR, C)
+    # float64 autograd through the library form
+    e64 = torch.tensor(e, dtype=torch.float64, device=dev, requires_grad=True)
+    hw = [torch.tensor(f[:, None], dtype=torch.float64, device=dev, requires_grad=True) for f in filt]
+    hb = [torch.tensor(b, dtype=torch.float64, device=dev, requires_grad=True) for b in bias]
+    vw = torch.zeros((1, 1, L, 1), dtype=torch.float64, device=dev)
+    ref = caser_convs(e64, vw, torch.zeros(1, dtype=torch.float64, device=dev), hw, hb)[:, d:]
+    (ref * tR.double()).sum().backward()
+    same = bool((N(arg) == o_arg).all())
+    tol = 1e-5 if same else 1e-2
+    r_ge = N(e64.grad)
+    np.testing.assert_allclose(N(ge), r_ge, rtol=1e-4, atol=tol * np.abs(r_ge).max())
+    r_gW = np.concatenate([N(w.grad).reshape(-1, d) for w in hw], 0)
+    np.testing.assert_allclose(N(gW), r_gW, rtol=1e-4, atol=tol * np.abs(r_gW).max())
+    r_gb = np.concatenate([N(b.grad) for b in hb])
+    np.testing.assert_allclose(N(gb), r_gb, rtol=1e-4, atol=tol * max(np.abs(r_gb).max(), 1e-30))
+    out2, arg2 = K.caser_hconv_forward(te, tW, tb, C, chunk_cols=max(C * L, 600))
+    ge2, gW2, gb2 = K.caser_hconv_backward(te, tW, arg2, tR, C)
+    for a, b_ in ((out, out2), (arg, arg2), (ge, ge2), (gW, gW2), (gb, gb2)):
+        assert torch.equal(a, b_)
+    # default chunking: the library GEMM runs other shapes (its summation order may differ), same result within rounding
+    out3, _ = K.caser_hconv_forward(te, tW, tb, C)
+    np.testing.assert_allclose(N(out3), o_out, rtol=1e-5, atol=1e-5 * scale)
