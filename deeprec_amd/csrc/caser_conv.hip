@@ -86,19 +86,19 @@ __global__ __launch_bounds__(256) void hconv_pool_fwd_kernel(const float* __rest
     }
 }
 
-// d e: one workgroup per sequence accumulates its [L, d] tile in LDS; column k of row p belongs to one thread
-// (k = tid % DP, p % (256 / DP) = tid / DP), contributions added in ascending (h, c, r)
-template <int DP>
+// d e: one workgroup per sequence accumulates its [L, d] tile in LDS; columns V (tid % LPR) .. +V-1 of row p belong to
+// one thread (p % (256 / LPR) = tid / LPR), contributions added in ascending (h, c, r)
+template <int V, int LPR>
 __global__ __launch_bounds__(256) void hconv_bwd_input_kernel(const float* __restrict__ gout,
                                                               const int32_t* __restrict__ arg,
                                                               const float* __restrict__ W, int64_t B, int L, int C,
                                                               int d, float* __restrict__ ge) {
     extern __shared__ float lds[];
-    constexpr int NG = 256 / DP;
+    constexpr int NG = 256 / LPR;
     float* acc = lds;
     float* gs = acc + L * d;
     int32_t* as = reinterpret_cast<int32_t*>(gs + C * L);
-    const int tid = threadIdx.x, k = tid % DP, grp = tid / DP;
+    const int tid = threadIdx.x, k = (tid % LPR) * V, grp = tid / LPR;
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         for (int idx = tid; idx < L * d; idx += 256) acc[idx] = 0.0f;
@@ -118,8 +118,15 @@ __global__ __launch_bounds__(256) void hconv_bwd_input_kernel(const float* __res
                     int r = (grp - t0) % NG;
                     if (r < 0) r += NG;
                     float* a = acc + (t0 + r) * d + k;
-#pragma unroll 4
-                    for (; r < h; r += NG, a += NG * d) *a = fmaf(g, w[(int64_t)r * d], *a);
+#pragma unroll 2
+                    for (; r < h; r += NG, a += NG * d) {
+                        float wv[V], av[V];
+                        vload<V>(wv, w + (int64_t)r * d);
+                        vload<V>(av, a);
+#pragma unroll
+                        for (int y = 0; y < V; ++y) av[y] = fmaf(g, wv[y], av[y]);
+                        vstore<V>(a, av);
+                    }
                 }
             }
         }
@@ -128,18 +135,19 @@ __global__ __launch_bounds__(256) void hconv_bwd_input_kernel(const float* __res
     }
 }
 
-// d W: one workgroup per (height, filter, batch chunk); the h x d partial lives in registers (thread = column k and
-// the rows r with r % (256 / DP) = tid / DP), sequences in ascending order; the chunks' partials are summed afterwards
-template <int DP>
+// d W: one workgroup per (height, filter, batch chunk); the h x d partial lives in registers (LPR lanes of V floats
+// per row; a thread keeps columns V (tid % LPR) .. +V-1 of the rows r with r % (256 / LPR) = tid / LPR), sequences in
+// ascending order; the chunks' partials are summed afterwards
+template <int V, int LPR>
 __global__ __launch_bounds__(256) void hconv_bwd_filter_kernel(const float* __restrict__ gout,
                                                                const int32_t* __restrict__ arg,
                                                                const float* __restrict__ e, int64_t B, int L, int C,
                                                                int d, int S, float* __restrict__ partial) {
-    constexpr int NG = 256 / DP;
-    constexpr int RMAX = HC_MAX_L / NG;
+    constexpr int NG = 256 / LPR;
+    constexpr int RMAX = (HC_MAX_L + NG - 1) / NG;
     __shared__ float gs[256];
     __shared__ int32_t as[256];
-    const int tid = threadIdx.x, k = tid % DP, grp = tid / DP;
+    const int tid = threadIdx.x, k = (tid % LPR) * V, grp = tid / LPR;
     const int64_t rows = hc_off(C, L + 1);
     // chunk-major: the workgroups resident together read the same few sequences' rows (L2), tall filters first
     const int npairs = L * C;
@@ -148,9 +156,11 @@ __global__ __launch_bounds__(256) void hconv_bwd_filter_kernel(const float* __re
     const int64_t o = (int64_t)(h - 1) * C + c;
     const int64_t per = (B + S - 1) / S;
     const int64_t b0 = s * per, b1 = (b0 + per < B) ? b0 + per : B;
-    float acc[RMAX];
+    float acc[RMAX][V];
 #pragma unroll
-    for (int i = 0; i < RMAX; ++i) acc[i] = 0.0f;
+    for (int i = 0; i < RMAX; ++i)
+#pragma unroll
+        for (int x = 0; x < V; ++x) acc[i][x] = 0.0f;
     for (int64_t bb = b0; bb < b1; bb += 256) {
         __syncthreads();
         if (bb + tid < b1) {
@@ -167,7 +177,12 @@ __global__ __launch_bounds__(256) void hconv_bwd_filter_kernel(const float* __re
 #pragma unroll
             for (int i = 0; i < RMAX; ++i) {
                 const int r = grp + i * NG;
-                if (r < h && k < d) acc[i] = fmaf(g, eb[(int64_t)r * d], acc[i]);
+                if (r < h && k < d) {
+                    float v[V];
+                    vload<V>(v, eb + (int64_t)r * d);
+#pragma unroll
+                    for (int y = 0; y < V; ++y) acc[i][y] = fmaf(g, v[y], acc[i][y]);
+                }
             }
         }
     }
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(256) void hconv_bwd_filter_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < RMAX; ++i) {
         const int r = grp + i * NG;
-        if (r < h && k < d) dst[(int64_t)r * d] = acc[i];
+        if (r < h && k < d) vstore<V>(dst + (int64_t)r * d, acc[i]);
     }
 }
 
@@ -224,20 +239,29 @@ extern "C" int32_t dr_caser_hconv_backward_input_f32(const float* gout, const in
     const size_t lds = ((size_t)L * d + 2 * (size_t)C * L) * 4;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(B < 2048 ? B : 2048);
-#define DR_HC(DP_)                                                                                                       \
+#define DR_HC(V_, LPR_)                                                                                                 \
     do {                                                                                                                 \
         if (lds > 48 * 1024)                                                                                             \
-            DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hconv_bwd_input_kernel<DP_>),                       \
+            DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hconv_bwd_input_kernel<V_, LPR_>),                  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-        DR_LAUNCH_NAMED("hconv_bwd_input_kernel", hconv_bwd_input_kernel<DP_>, dim3(grid), dim3(256), lds, st, gout, arg, \
-                        W, B, (int)L, (int)C, (int)d, ge);                                                               \
+        DR_LAUNCH_NAMED("hconv_bwd_input_kernel", (hconv_bwd_input_kernel<V_, LPR_>), dim3(grid), dim3(256), lds, st,   \
+                        gout, arg, W, B, (int)L, (int)C, (int)d, ge);                                                    \
     } while (0)
-    if (d <= 64)
-        DR_HC(64);
-    else if (d <= 128)
-        DR_HC(128);
-    else
-        DR_HC(256);
+    if (d % 4 == 0 && ((uintptr_t)W % 16 == 0)) {
+        if (d <= 64)
+            DR_HC(4, 16);
+        else if (d <= 128)
+            DR_HC(4, 32);
+        else
+            DR_HC(4, 64);
+    } else {
+        if (d <= 64)
+            DR_HC(1, 64);
+        else if (d <= 128)
+            DR_HC(1, 128);
+        else
+            DR_HC(1, 256);
+    }
 #undef DR_HC
     DR_CHECK_LAUNCH("hconv_bwd_input_kernel");
     return DR_OK;
@@ -251,15 +275,26 @@ extern "C" int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const i
     DR_REQUIRE(gout && arg && e && partial, "dr_caser_hconv_backward_filter_f32: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
     const int grid = L * C * S;
-    if (d <= 64)
-        DR_LAUNCH_NAMED("hconv_bwd_filter_kernel", hconv_bwd_filter_kernel<64>, dim3(grid), dim3(256), 0, st, gout, arg, e,
-                        B, (int)L, (int)C, (int)d, (int)S, partial);
-    else if (d <= 128)
-        DR_LAUNCH_NAMED("hconv_bwd_filter_kernel", hconv_bwd_filter_kernel<128>, dim3(grid), dim3(256), 0, st, gout, arg,
-                        e, B, (int)L, (int)C, (int)d, (int)S, partial);
-    else
-        DR_LAUNCH_NAMED("hconv_bwd_filter_kernel", hconv_bwd_filter_kernel<256>, dim3(grid), dim3(256), 0, st, gout, arg,
-                        e, B, (int)L, (int)C, (int)d, (int)S, partial);
+    const bool v4 = d % 4 == 0 && (((uintptr_t)e | (uintptr_t)partial) % 16 == 0);
+#define DR_HF(V_, LPR_)                                                                                                  \
+    DR_LAUNCH_NAMED("hconv_bwd_filter_kernel", (hconv_bwd_filter_kernel<V_, LPR_>), dim3(grid), dim3(256), 0, st, gout, \
+                    arg, e, B, (int)L, (int)C, (int)d, (int)S, partial)
+    if (v4) {
+        if (d <= 64)
+            DR_HF(4, 16);
+        else if (d <= 128)
+            DR_HF(4, 32);
+        else
+            DR_HF(4, 64);
+    } else {
+        if (d <= 64)
+            DR_HF(1, 64);
+        else if (d <= 128)
+            DR_HF(1, 128);
+        else
+            DR_HF(1, 256);
+    }
+#undef DR_HF
     DR_CHECK_LAUNCH("hconv_bwd_filter_kernel");
     return DR_OK;
 }
