@@ -634,6 +634,33 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ w
     }
 }
 
+// the same update on float4 elements (count % 4 == 0, 16-byte aligned tensors): four times fewer, wider memory
+// instructions on what is a pure streaming pass (Caser's [U, d L] table: 25.6 GB x 6 streams per step)
+template <int KIND>
+__global__ __launch_bounds__(256) void dense_update4_kernel(float4* __restrict__ w, float4* __restrict__ s0p,
+                                                            float4* __restrict__ s1p, const float4* __restrict__ grad,
+                                                            int64_t count4, OptP o) {
+    o = resolve(o);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (int64_t)gridDim.x * 256) {
+        const float4 w4 = w[i];
+        float4 g4 = grad ? grad[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b4 = a4;
+        if constexpr (KIND != DR_OPT_SGD) a4 = s0p[i];
+        if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) b4 = s1p[i];
+        float wv[4] = {w4.x, w4.y, w4.z, w4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            float g = gv[x];
+            if (o.reg_mode != DR_REG_NONE) g = g + o.reg * wv[x];
+            opt_apply<KIND>(wv[x], av[x], bv[x], g, o);
+        }
+        w[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+        if constexpr (KIND != DR_OPT_SGD) s0p[i] = make_float4(av[0], av[1], av[2], av[3]);
+        if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) s1p[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+    }
+}
+
 // one sub-wave per row: sequential-in-lane partial sums of squares, butterfly, scale
 template <int V, int LPR>
 __global__ __launch_bounds__(256) void rownorm_clip_kernel(float* __restrict__ t, int64_t rows, int k, float clip) {
@@ -939,6 +966,24 @@ extern "C" int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, con
     DR_REQUIRE(w != nullptr, "dr_dense_update_f32: w is NULL");
     OptP o = make_optp(opt);
     hipStream_t st = (hipStream_t)stream;
+    const bool v4 = count % 4 == 0 &&
+                    (((uintptr_t)w | (uintptr_t)slot0 | (uintptr_t)slot1 | (uintptr_t)grad) % 16 == 0);
+    if (v4) {
+        const int64_t c4 = count / 4;
+        const int grid = grid_for(c4, 256, 2);
+#define DR_DU4(KIND_)                                                                                              \
+    DR_LAUNCH((dense_update4_kernel<KIND_>), dim3(grid), dim3(256), 0, st, (float4*)w, (float4*)slot0, (float4*)slot1, \
+              (const float4*)grad, c4, o)
+        switch (opt->kind) {
+            case DR_OPT_SGD: DR_DU4(DR_OPT_SGD); break;
+            case DR_OPT_ADAM: DR_DU4(DR_OPT_ADAM); break;
+            case DR_OPT_ADAGRAD: DR_DU4(DR_OPT_ADAGRAD); break;
+            default: DR_DU4(DR_OPT_RMSPROP); break;
+        }
+#undef DR_DU4
+        DR_CHECK_LAUNCH("dr_dense_update_f32");
+        return DR_OK;
+    }
     int grid = grid_for(count, 256, 4);
     switch (opt->kind) {
         case DR_OPT_SGD:
