@@ -44,17 +44,29 @@ template <int V>
 __device__ __forceinline__ void att_stage_q(const float* __restrict__ pre_b, int L, int d, const AttLayout& A,
                                             float* __restrict__ q) {
     const int cpr = d / V;
-    for (int idx = threadIdx.x; idx < A.LP * cpr; idx += 256) {
-        const int l = idx / cpr, c = idx - l * cpr;
-        float r[V];
-        if (l < L) {
-            vload<V>(r, pre_b + (int64_t)l * d + c * V);
-        } else {
+    // four row pieces in flight per thread before the first LDS store
+    for (int base = 0; base < A.LP * cpr; base += 256 * 4) {
+        float r[4][V];
 #pragma unroll
-            for (int x = 0; x < V; ++x) r[x] = 0.0f;
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            const int l = idx / cpr, c = idx - l * cpr;
+            if (l < L) {
+                vload<V>(r[u], pre_b + (int64_t)l * d + c * V);
+            } else {
+#pragma unroll
+                for (int x = 0; x < V; ++x) r[u][x] = 0.0f;
+            }
         }
 #pragma unroll
-        for (int x = 0; x < V; ++x) q[l * A.DS + c * V + x] = fmaxf(r[x], 0.0f);
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            const int l = idx / cpr, c = idx - l * cpr;
+            if (l < A.LP) {
+#pragma unroll
+                for (int x = 0; x < V; ++x) q[l * A.DS + c * V + x] = fmaxf(r[u][x], 0.0f);
+            }
+        }
     }
 }
 
@@ -155,8 +167,20 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
             const int col = tid & (dp - 1), g = tid / dp;
             float acc = 0.0f;
             if (col < d) {
-#pragma unroll 4
-                for (int m = g; m < L; m += G) acc = fmaf(c[m], v_b[(int64_t)m * d + col], acc);
+                // sixteen value rows in flight per thread (a plain loop waits for every load in turn)
+                for (int m0 = g; m0 < L; m0 += 16 * G) {
+                    float x[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int m = m0 + u * G;
+                        x[u] = m < L ? v_b[(int64_t)m * d + col] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int m = m0 + u * G;
+                        if (m < L) acc = fmaf(c[m], x[u], acc);
+                    }
+                }
             }
             if (G > 1) {
                 part[tid] = acc;
@@ -196,20 +220,48 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restr
         const float* v_b = v + b * L * d;
         __syncthreads();
         att_stage_q<V>(pre_b, L, d, A, q);
-        for (int idx = tid; idx < A.LP * A.LP; idx += 256) {
-            const int l = idx / A.LP, m = idx - l * A.LP;
-            S[l * A.SS + m] = (l < L && m < L) ? s_in[(b * L + l) * L + m] : 0.0f;
+        for (int base = 0; base < A.LP * A.LP; base += 256 * 4) {
+            float sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int l = idx / A.LP, m = idx - l * A.LP;
+                sv[u] = (l < L && m < L) ? s_in[(b * L + l) * L + m] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int l = idx / A.LP, m = idx - l * A.LP;
+                if (l < A.LP) S[l * A.SS + m] = sv[u];
+            }
         }
         for (int t = tid; t < d; t += 256) go[t] = gout[b * d + t];
         __syncthreads();
         att_colsum(S, L, A.SS, c);
         // dc[m] = <gout, v[m]> / L: one wavefront per value row, columns strided over the lanes
-        for (int m = wave; m < L; m += 4) {
-            float acc = 0.0f;
-            for (int t = lane; t < d; t += 64) acc = fmaf(go[t], v_b[(int64_t)m * d + t], acc);
+        // (four rows x up to four column pieces in flight per lane)
+        for (int m0 = wave; m0 < L; m0 += 16) {
+            float x[4][4];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-            if (lane == 0) dc[m] = acc / fL;
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + 4 * u, t = lane + 64 * j;
+                    x[u][j] = (m < L && t < d) ? v_b[(int64_t)m * d + t] : 0.0f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = m0 + 4 * u;
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = lane + 64 * j;
+                    if (t < d) acc = fmaf(go[t], x[u][j], acc);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if (lane == 0 && m < L) dc[m] = acc / fL;
+            }
         }
         __syncthreads();
         // direct part of the value gradient: dv[m] = (c[m] / L) gout

@@ -24,7 +24,7 @@ __host__ __device__ static inline int64_t hc_off(int C, int h) { return (int64_t
 // Pooling over a column chunk of G that holds heights h0 .. h1.  One workgroup per (sequence, height, band of filters):
 // the band's [L, cb * h] slab of G (cb = as many filters as fit HC_BAND floats per row) is read coalesced into LDS (odd
 // row stride), one thread per (filter, position) sums its window's diagonal, one thread per filter takes the maximum.
-constexpr int HC_BAND = 240;
+constexpr int HC_BAND = 120;   // 24 KB of LDS per workgroup at L = 50: six workgroups per CU hide the slab loads' latency
 
 __host__ __device__ static inline int hc_cb(int C, int h) {
     int cb = HC_BAND / h;
@@ -56,9 +56,22 @@ __global__ __launch_bounds__(256) void hconv_pool_fwd_kernel(const float* __rest
     for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
         __syncthreads();
         const float* src = G + b * L * ldg + col;
-        for (int idx = tid; idx < L * Wd; idx += 256) {
-            const int p = idx / Wd, x = idx - p * Wd;
-            X[p * Wp + x] = src[(int64_t)p * ldg + x];
+        // eight loads in flight per thread before the first LDS store (written as X[..] = src[..] in one loop the
+        // compiler waits for each load before its store: one memory round trip per element)
+        for (int base = 0; base < L * Wd; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int p = idx / Wd, x = idx - p * Wd;
+                v[u] = idx < L * Wd ? src[(int64_t)p * ldg + x] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int p = idx / Wd, x = idx - p * Wd;
+                if (idx < L * Wd) X[p * Wp + x] = v[u];
+            }
         }
         __syncthreads();
         for (int it = tid; it < cb * T; it += 256) {
