@@ -367,20 +367,24 @@ extern "C" int32_t dr_attn_pool_forward_f32(const float* pre, const float* v, in
     if (int rc = att_check("dr_attn_pool_forward_f32", B, L, d)) return rc;
     if (B == 0) return DR_OK;
     DR_REQUIRE(pre && v && out && s, "dr_attn_pool_forward_f32: NULL pointer");
-    const bool v4 = d % 4 == 0 && ((uintptr_t)pre % 16 == 0);
+    const int V = (d % 4 == 0 && (uintptr_t)pre % 16 == 0) ? 4 : ((d % 2 == 0 && (uintptr_t)pre % 8 == 0) ? 2 : 1);
     const size_t lds = (size_t)att_layout(L, d).total * 4;
     const float sd = (float)sqrt((double)d);
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
-    if (v4) {
-        if (int rc = att_grid(attn_pool_fwd_kernel<4>, B, lds, &grid)) return rc;
-        DR_LAUNCH_NAMED("attn_pool_fwd_kernel", attn_pool_fwd_kernel<4>, dim3(grid), dim3(256), lds, st, pre, v, B,
-                        (int)L, (int)d, sd, out, s);
-    } else {
-        if (int rc = att_grid(attn_pool_fwd_kernel<1>, B, lds, &grid)) return rc;
-        DR_LAUNCH_NAMED("attn_pool_fwd_kernel", attn_pool_fwd_kernel<1>, dim3(grid), dim3(256), lds, st, pre, v, B,
-                        (int)L, (int)d, sd, out, s);
-    }
+#define DR_AF(V_)                                                                                                    \
+    do {                                                                                                             \
+        if (int rc = att_grid(attn_pool_fwd_kernel<V_>, B, lds, &grid)) return rc;                                   \
+        DR_LAUNCH_NAMED("attn_pool_fwd_kernel", attn_pool_fwd_kernel<V_>, dim3(grid), dim3(256), lds, st, pre, v, B, \
+                        (int)L, (int)d, sd, out, s);                                                                 \
+    } while (0)
+    if (V == 4)
+        DR_AF(4);
+    else if (V == 2)
+        DR_AF(2);
+    else
+        DR_AF(1);
+#undef DR_AF
     DR_CHECK_LAUNCH("attn_pool_fwd_kernel");
     return DR_OK;
 }
@@ -390,20 +394,24 @@ extern "C" int32_t dr_attn_pool_backward_f32(const float* pre, const float* v, c
     if (int rc = att_check("dr_attn_pool_backward_f32", B, L, d)) return rc;
     if (B == 0) return DR_OK;
     DR_REQUIRE(pre && v && s && gout && dpre && dv, "dr_attn_pool_backward_f32: NULL pointer");
-    const bool v4 = d % 4 == 0 && ((uintptr_t)pre % 16 == 0);
+    const int V = (d % 4 == 0 && (uintptr_t)pre % 16 == 0) ? 4 : ((d % 2 == 0 && (uintptr_t)pre % 8 == 0) ? 2 : 1);
     const size_t lds = (size_t)att_layout(L, d).total * 4;
     const float sd = (float)sqrt((double)d);
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
-    if (v4) {
-        if (int rc = att_grid(attn_pool_bwd_kernel<4>, B, lds, &grid)) return rc;
-        DR_LAUNCH_NAMED("attn_pool_bwd_kernel", attn_pool_bwd_kernel<4>, dim3(grid), dim3(256), lds, st, pre, v, s, gout,
-                        B, (int)L, (int)d, sd, dpre, dv);
-    } else {
-        if (int rc = att_grid(attn_pool_bwd_kernel<1>, B, lds, &grid)) return rc;
-        DR_LAUNCH_NAMED("attn_pool_bwd_kernel", attn_pool_bwd_kernel<1>, dim3(grid), dim3(256), lds, st, pre, v, s, gout,
-                        B, (int)L, (int)d, sd, dpre, dv);
-    }
+#define DR_AB(V_)                                                                                                      \
+    do {                                                                                                               \
+        if (int rc = att_grid(attn_pool_bwd_kernel<V_>, B, lds, &grid)) return rc;                                     \
+        DR_LAUNCH_NAMED("attn_pool_bwd_kernel", attn_pool_bwd_kernel<V_>, dim3(grid), dim3(256), lds, st, pre, v, s,  \
+                        gout, B, (int)L, (int)d, sd, dpre, dv);                                                        \
+    } while (0)
+    if (V == 4)
+        DR_AB(4);
+    else if (V == 2)
+        DR_AB(2);
+    else
+        DR_AB(1);
+#undef DR_AB
     DR_CHECK_LAUNCH("attn_pool_bwd_kernel");
     return DR_OK;
 }

@@ -267,6 +267,13 @@ extern "C" int32_t dr_caser_hconv_backward_input_f32(const float* gout, const in
             DR_HC(4, 32);
         else
             DR_HC(4, 64);
+    } else if (d % 2 == 0 && ((uintptr_t)W % 8 == 0)) {
+        if (d <= 64)
+            DR_HC(2, 32);
+        else if (d <= 128)
+            DR_HC(2, 64);
+        else
+            DR_HC(2, 128);
     } else {
         if (d <= 64)
             DR_HC(1, 64);
@@ -292,6 +299,7 @@ extern "C" int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const i
 #define DR_HF(V_, LPR_)                                                                                                  \
     DR_LAUNCH_NAMED("hconv_bwd_filter_kernel", (hconv_bwd_filter_kernel<V_, LPR_>), dim3(grid), dim3(256), 0, st, gout, \
                     arg, e, B, (int)L, (int)C, (int)d, (int)S, partial)
+    const bool v2 = d % 2 == 0 && (((uintptr_t)e | (uintptr_t)partial) % 8 == 0);
     if (v4) {
         if (d <= 64)
             DR_HF(4, 16);
@@ -299,6 +307,13 @@ extern "C" int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const i
             DR_HF(4, 32);
         else
             DR_HF(4, 64);
+    } else if (v2) {          // the reference's default num_factor = 150
+        if (d <= 64)
+            DR_HF(2, 32);
+        else if (d <= 128)
+            DR_HF(2, 64);
+        else
+            DR_HF(2, 128);
     } else {
         if (d <= 64)
             DR_HF(1, 64);
