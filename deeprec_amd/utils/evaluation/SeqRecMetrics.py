@@ -69,9 +69,11 @@ def _rank(self, users, U, I, kind, U2=None, I2=None, alpha=0.0, bias=None, score
     tp, ti = pack_csr(masked, dev)
     gp, gi = pack_csr(tgt, dev)
     if scores is not None:
-        _, _, rank = Kn.topk_rank(scores, 50, train=(tp, ti), targets=(gp, gi))
+        # HR@50 / MRR / AUC depend on the ranks of the held-out items only (SeqRecMetrics.py:33,59,75-80): no top-50
+        # list is kept (K = 1), the rank counters are the same
+        _, _, rank = Kn.topk_rank(scores, 1, train=(tp, ti), targets=(gp, gi))
     else:
-        _, _, rank = Kn.score_topk(_t(U, dev), _t(I, dev), 50, score_kind=kind,
+        _, _, rank = Kn.score_topk(_t(U, dev), _t(I, dev), 1, score_kind=kind,
                                    U2=None if U2 is None else _t(U2, dev), I2=None if I2 is None else _t(I2, dev),
                                    alpha=alpha, item_bias=None if bias is None else _t(bias, dev).reshape(-1),
                                    train=(tp, ti), targets=(gp, gi))

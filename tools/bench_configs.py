@@ -144,8 +144,8 @@ def main():
         del m
         torch.cuda.empty_cache()
     say("   C5 eval")
-    # ---- C5 evaluation (SeqRecMetrics.evaluate1 / evaluate_caser): all items for a block of users, top-50 + rank of
-    # one held-out item, 50 masked train items per user; AttRec's two-distance score and Caser's dot + item bias
+    # ---- C5 evaluation (SeqRecMetrics.evaluate1 / evaluate_caser): all items for a block of users, rank of one held-out
+    # item (what HR@50 / MRR / AUC need; the evaluators keep no top-K list: K = 1), 50 masked train items per user; AttRec's two-distance score and Caser's dot + item bias
     Nu, Ni, d = 65536, 100_000, 128
     g = torch.Generator(device=dev)
     g.manual_seed(5)
@@ -155,7 +155,7 @@ def main():
     tp = (torch.arange(Nu + 1, device=dev) * 50).to(torch.int32)
     tg = torch.randint(1, Ni, (Nu,), device=dev, generator=g).to(torch.int32)
     gp = torch.arange(Nu + 1, device=dev).to(torch.int32)
-    ms = timed(lambda: K.score_topk(U1, I1, 50, score_kind=K.SCORE_TWO_DIST, U2=U2, I2=I2, alpha=0.2, train=(tp, tr),
+    ms = timed(lambda: K.score_topk(U1, I1, 1, score_kind=K.SCORE_TWO_DIST, U2=U2, I2=I2, alpha=0.2, train=(tp, tr),
                                     targets=(gp, tg)), 5, 1)
     fl = 2.0 * Nu * Ni * 2 * d
     out["C5_AttRec"]["eval_ms_65536_users_x_100k_items"] = ms
@@ -163,7 +163,7 @@ def main():
     out["C5_AttRec"]["eval_TFLOPs"] = fl / ms / 1e9
     Uc, Wc = torch.randn(Nu, 2 * d, device=dev, generator=g) * 0.1, torch.randn(Ni, 2 * d, device=dev, generator=g) * 0.1
     bc = torch.randn(Ni, device=dev, generator=g) * 0.1
-    ms = timed(lambda: K.score_topk(Uc, Wc, 50, item_bias=bc, train=(tp, tr), targets=(gp, tg)), 5, 1)
+    ms = timed(lambda: K.score_topk(Uc, Wc, 1, item_bias=bc, train=(tp, tr), targets=(gp, tg)), 5, 1)
     out["C5_Caser"]["eval_ms_65536_users_x_100k_items"] = ms
     out["C5_Caser"]["eval_users_per_s"] = Nu / ms * 1e3
     out["C5_Caser"]["eval_TFLOPs"] = fl / ms / 1e9
