@@ -104,9 +104,15 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
         __syncthreads();   // the previous sequence's readers are done with q / S / c
         att_stage_q<V>(pre_b, L, d, A, q);
         __syncthreads();
-        // ---- logits: one 4x4 tile of q q^T per thread, k ascending ------------------------------------
-        if (tid < nT * nT) {
-            const int ti = tid / nT, tj = tid - ti * nT;
+        // ---- logits: one 4x4 tile of q q^T per thread, k ascending; q q^T is symmetric (and fmaf(a, b, c) =
+        // fmaf(b, a, c)), so only the tiles on and above the diagonal are computed and each is stored twice
+        if (tid < nT * (nT + 1) / 2) {
+            int ti = 0, rem = tid;
+            while (rem >= nT - ti) {
+                rem -= nT - ti;
+                ++ti;
+            }
+            const int tj = ti + rem;
             const float* qa = q + (4 * ti) * A.DS;
             const float* qb = q + (4 * tj) * A.DS;
             float acc[4][4];
@@ -129,7 +135,11 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
 #pragma unroll
             for (int x = 0; x < 4; ++x)
 #pragma unroll
-                for (int y = 0; y < 4; ++y) S[(4 * ti + x) * A.SS + 4 * tj + y] = acc[x][y] / sqrt_d;
+                for (int y = 0; y < 4; ++y) {
+                    const float sc = acc[x][y] / sqrt_d;
+                    S[(4 * ti + x) * A.SS + 4 * tj + y] = sc;
+                    S[(4 * tj + y) * A.SS + 4 * ti + x] = sc;
+                }
         }
         __syncthreads();
         // ---- softmax over each row: four lanes per row ------------------------------------------------
@@ -298,21 +308,34 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restr
             }
         }
         __syncthreads();
-        // dpre[l][col] = relu'(pre) * sum_m G[l][m] q[m][col]: four rows per thread and pass, m ascending
+        // dpre[l][col] = relu'(pre) * sum_m G[l][m] q[m][col], m ascending: eight rows x two columns per thread (ten LDS
+        // reads per sixteen multiply-adds; the G reads are wave-wide broadcasts)
         {
-            const int col = tid & (dp - 1), g = tid / dp;
-            if (col < d) {
-                for (int l0 = 4 * g; l0 < A.LP; l0 += 4 * G) {
-                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                    for (int m = 0; m < L; ++m) {
-                        const float qv = q[m * A.DS + col];
+            const int hp = dp / 2 > 0 ? dp / 2 : 1;          // threads per row group: columns col and col + hp
+            const int col = tid % hp, g = tid / hp, NGR = 256 / hp;
+            const bool c0 = col < d, c1 = col + hp < d;
+            if (c0) {
+                for (int l0 = 8 * g; l0 < A.LP; l0 += 8 * NGR) {
+                    float acc0[8], acc1[8];
 #pragma unroll
-                        for (int x = 0; x < 4; ++x) acc[x] = fmaf(S[(l0 + x) * A.SS + m], qv, acc[x]);
+                    for (int x = 0; x < 8; ++x) acc0[x] = acc1[x] = 0.0f;
+                    for (int m = 0; m < L; ++m) {
+                        const float q0 = q[m * A.DS + col];
+                        const float q1 = c1 ? q[m * A.DS + col + hp] : 0.0f;
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) {
+                            const float gv = (l0 + x < A.LP) ? S[(l0 + x) * A.SS + m] : 0.0f;
+                            acc0[x] = fmaf(gv, q0, acc0[x]);
+                            acc1[x] = fmaf(gv, q1, acc1[x]);
+                        }
                     }
 #pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        if (l0 + x < L)
-                            dpre[(b * L + l0 + x) * d + col] = q[(l0 + x) * A.DS + col] > 0.0f ? acc[x] : 0.0f;
+                    for (int x = 0; x < 8; ++x)
+                        if (l0 + x < L) {
+                            float* dst = dpre + (b * L + l0 + x) * d;
+                            dst[col] = q[(l0 + x) * A.DS + col] > 0.0f ? acc0[x] : 0.0f;
+                            if (c1) dst[col + hp] = q[(l0 + x) * A.DS + col + hp] > 0.0f ? acc1[x] : 0.0f;
+                        }
                 }
             }
         }
