@@ -292,8 +292,13 @@ extern "C" int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const i
                                                       void* stream) {
     if (int rc = hc_check("dr_caser_hconv_backward_filter_f32", B, L, C, d)) return rc;
     DR_REQUIRE(S >= 1 && S <= 64, "dr_caser_hconv_backward_filter_f32: 1 <= S <= 64 batch chunks");
-    DR_REQUIRE(gout && arg && e && partial, "dr_caser_hconv_backward_filter_f32: NULL pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {       // no sequences: the partial sums are zero
+        DR_REQUIRE(partial != nullptr, "dr_caser_hconv_backward_filter_f32: partial is NULL");
+        DR_HIP(hipMemsetAsync(partial, 0, (size_t)S * (size_t)hc_off(C, L + 1) * (size_t)d * 4, st));
+        return DR_OK;
+    }
+    DR_REQUIRE(gout && arg && e && partial, "dr_caser_hconv_backward_filter_f32: NULL pointer");
     const int grid = L * C * S;
     const bool v4 = d % 4 == 0 && (((uintptr_t)e | (uintptr_t)partial) % 16 == 0);
 #define DR_HF(V_, LPR_)                                                                                                  \

@@ -847,3 +847,21 @@ def test_caser_hconv_forward_backward(dev, B, L, d, C):
     # default chunking: the library GEMM runs other shapes (its summation order may differ), same result within rounding
     out3, _ = K.caser_hconv_forward(te, tW, tb, C)
     np.testing.assert_allclose(N(out3), o_out, rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_caser_hconv_empty_batch_and_limits(dev):
+    from deeprec_amd import kernels as K
+    from deeprec_amd._abi import DeepRecError
+    L, d, C = 4, 8, 2
+    W = torch.randn(K.hconv_rows(C, L + 1), d, device=dev)
+    b = torch.zeros(C * L, device=dev)
+    e = torch.zeros((0, L, d), device=dev)
+    out, arg = K.caser_hconv_forward(e, W, b, C)
+    assert out.shape == (0, C * L) and arg.shape == (0, C * L)
+    ge, gW, gb = K.caser_hconv_backward(e, W, arg, torch.zeros((0, C * L), device=dev), C)
+    assert ge.shape == (0, L, d) and float(gW.abs().max()) == 0.0 and float(gb.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        K.caser_hconv_forward(torch.zeros((2, L, d), device=dev), W[:-1], b, C)
+    big = torch.zeros((1, 65, 4), device=dev)
+    with pytest.raises(DeepRecError):
+        K.caser_hconv_forward(big, torch.zeros((K.hconv_rows(1, 66), 4), device=dev), torch.zeros(65, device=dev), 1)
