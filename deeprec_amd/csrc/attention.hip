@@ -5,12 +5,12 @@
 //   w = s with the diagonal zeroed AFTER the softmax (AttRec.py:178-180)
 //   out = mean_l (w v)[l] = (1 / L) sum_m c[m] v[m],  c[m] = sum_{l != m} s[l][m],   v = Q[item_seq]   [B, L, d]
 //
-// One workgroup per sequence: q lives in LDS (odd row stride, so the 4x4 register tiles of the L x L score matrix read
-// it without bank conflicts), the score matrix never leaves LDS except as the saved softmax the backward needs, and the
-// [B, L, L] x [B, L, d] product collapses to one weighted sum of the L value rows.  Under autograd this was ~25 library
-// launches (two batched GEMMs, softmax, mask, mean and their backward) over [B, L, d] temporaries.  fp32 VALU work on
-// L x L x d = 320 k multiply-adds per sequence: bound by the two [B, L, d] streams it reads, not by arithmetic, so no
-// MFMA here.  Deterministic: every sum has a fixed order.
+// One workgroup per sequence: q lives in LDS (row stride = 2 mod 4: the operand reads of an MFMA hit 64 different banks),
+// q q^T and the backward's G q run on v_mfma_f32_32x32x2_f32 (one 32 x 32 tile per wavefront), the score matrix never
+// leaves LDS except as the saved softmax the backward needs, and the [B, L, L] x [B, L, d] product collapses to one
+// weighted sum of the L value rows.  Under autograd this was ~25 library
+// launches (two batched GEMMs, softmax, mask, mean and their backward) over [B, L, d] temporaries.  Deterministic: every
+// sum has a fixed order (the MFMA accumulates k in ascending order like an fmaf chain).
 #include "dr_common.h"
 
 namespace dr {
@@ -18,24 +18,29 @@ namespace dr {
 constexpr int ATT_MAX_L = 64;
 constexpr int ATT_MAX_D = 256;
 
+typedef float att_f32x16 __attribute__((ext_vector_type(16)));
+
 struct AttLayout {
-    int LP, DS, SS;       // L rounded up to 4; row stride of q (odd); row stride of the score matrix
+    int LP, DK, DS, SS;   // L rounded up to 4; d rounded up to 2; row strides of q and of the score matrix
     int q, S, c, dc, rd, go, part, total;   // offsets in floats
 };
 
-static inline __host__ __device__ AttLayout att_layout(int L, int d) {
+// Row strides are = 2 (mod 4): the 64 operand reads of one v_mfma_f32_32x32x2_f32 (32 rows x 2 adjacent k) then fall
+// into 64 different LDS banks.  The forward needs c + part behind the matrices, the backward c, dc, rd, go.
+static inline __host__ __device__ AttLayout att_layout(int L, int d, bool backward = false) {
     AttLayout a;
     a.LP = (L + 3) / 4 * 4;
-    a.DS = d | 1;
-    a.SS = a.LP + 1;
+    a.DK = (d + 1) / 2 * 2;
+    a.DS = (a.DK % 4 == 0) ? a.DK + 2 : a.DK;
+    a.SS = a.LP + 2;
     a.q = 0;
     a.S = a.q + a.LP * a.DS;
     a.c = a.S + a.LP * a.SS;
     a.dc = a.c + ATT_MAX_L;
     a.rd = a.dc + ATT_MAX_L;
     a.go = a.rd + ATT_MAX_L;
-    a.part = a.go + ATT_MAX_D;
-    a.total = a.part + 256;
+    a.part = a.c + ATT_MAX_L;                         // forward only: aliases dc / rd / go
+    a.total = backward ? a.go + ATT_MAX_D : a.part + 256;
     return a;
 }
 
@@ -68,6 +73,8 @@ __device__ __forceinline__ void att_stage_q(const float* __restrict__ pre_b, int
             }
         }
     }
+    if (A.DK != d)       // odd d: the k-pair of the last MFMA step reads one column past the row
+        for (int l = threadIdx.x; l < A.LP; l += 256) q[l * A.DS + d] = 0.0f;
 }
 
 // c[m] = sum over l != m of S[l][m], l ascending
@@ -104,66 +111,61 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
         __syncthreads();   // the previous sequence's readers are done with q / S / c
         att_stage_q<V>(pre_b, L, d, A, q);
         __syncthreads();
-        // ---- logits: one 4x4 tile of q q^T per thread, k ascending; q q^T is symmetric (and fmaf(a, b, c) =
-        // fmaf(b, a, c)), so only the tiles on and above the diagonal are computed and each is stored twice
-        if (tid < nT * (nT + 1) / 2) {
-            int ti = 0, rem = tid;
-            while (rem >= nT - ti) {
-                rem -= nT - ti;
-                ++ti;
-            }
-            const int tj = ti + rem;
-            const float* qa = q + (4 * ti) * A.DS;
-            const float* qb = q + (4 * tj) * A.DS;
-            float acc[4][4];
+        // ---- logits: q q^T on the matrix cores, one 32 x 32 tile per wavefront (L <= 64: at most 2 x 2 tiles).
+        // v_mfma_f32_32x32x2_f32 accumulates in ascending k like an fp32 fmaf chain; lane l feeds row l % 32 of either
+        // operand at k = 2 step + l / 32.  Rows beyond LP are clamped (their products are never stored).
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+            const int nMt = L > 32 ? 2 : 1;
+            if (wave < nMt * nMt) {
+                const int I = wave / nMt, J = wave - I * nMt;
+                const int ra = min(32 * I + (lane & 31), A.LP - 1), rb = min(32 * J + (lane & 31), A.LP - 1);
+                const float* pa = q + ra * A.DS + (lane >> 5);
+                const float* pb = q + rb * A.DS + (lane >> 5);
+                att_f32x16 acc;
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                for (int k = 0; k < A.DK; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+                const int col = 32 * J + (lane & 31);
 #pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = 0.0f;
-            for (int t = 0; t < d; ++t) {
-                float a[4], bb[4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    a[x] = qa[x * A.DS + t];
-                    bb[x] = qb[x * A.DS + t];
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * I + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < A.LP && col < A.LP) S[row * A.SS + col] = acc[r] / sqrt_d;
                 }
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) acc[x][y] = fmaf(a[x], bb[y], acc[x][y]);
             }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    const float sc = acc[x][y] / sqrt_d;
-                    S[(4 * ti + x) * A.SS + 4 * tj + y] = sc;
-                    S[(4 * tj + y) * A.SS + 4 * ti + x] = sc;
-                }
         }
         __syncthreads();
-        // ---- softmax over each row: four lanes per row ------------------------------------------------
+        // ---- softmax over each row: four lanes per row, the lane's <= 16 logits stay in registers -----------------
         {
             const int row = tid >> 2, sub = tid & 3;
             const bool on = row < L;
+            float e[ATT_MAX_L / 4];
             float mx = -INFINITY;
-            if (on)
-                for (int m = sub; m < L; m += 4) mx = fmaxf(mx, S[row * A.SS + m]);
+#pragma unroll
+            for (int i = 0; i < ATT_MAX_L / 4; ++i) {
+                const int m = sub + 4 * i;
+                e[i] = (on && m < L) ? S[row * A.SS + m] : -INFINITY;
+                mx = fmaxf(mx, e[i]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
             float sum = 0.0f;
-            if (on)
-                for (int m = sub; m < L; m += 4) {
-                    const float e = expf(S[row * A.SS + m] - mx);
-                    S[row * A.SS + m] = e;
-                    sum += e;
+#pragma unroll
+            for (int i = 0; i < ATT_MAX_L / 4; ++i) {
+                const int m = sub + 4 * i;
+                if (on && m < L) {
+                    e[i] = expf(e[i] - mx);
+                    sum += e[i];
                 }
+            }
             sum += __shfl_xor(sum, 1, 64);
             sum += __shfl_xor(sum, 2, 64);
-            if (on) {
-                float* so = s_out + (b * L + row) * L;
-                for (int m = sub; m < L; m += 4) {
-                    const float p = S[row * A.SS + m] / sum;
+            float* so = s_out + (b * L + row) * L;
+#pragma unroll
+            for (int i = 0; i < ATT_MAX_L / 4; ++i) {
+                const int m = sub + 4 * i;
+                if (on && m < L) {
+                    const float p = e[i] / sum;
                     S[row * A.SS + m] = p;
                     so[m] = p;
                 }
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restr
                                                             float sqrt_d, float* __restrict__ dpre,
                                                             float* __restrict__ dv) {
     extern __shared__ float lds[];
-    const AttLayout A = att_layout(L, d);
+    const AttLayout A = att_layout(L, d, true);
     float* q = lds + A.q;
     float* S = lds + A.S;
     float* c = lds + A.c;
@@ -308,34 +310,28 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restr
             }
         }
         __syncthreads();
-        // dpre[l][col] = relu'(pre) * sum_m G[l][m] q[m][col], m ascending: eight rows x two columns per thread (ten LDS
-        // reads per sixteen multiply-adds; the G reads are wave-wide broadcasts)
+        // dpre[l][col] = relu'(pre) * sum_m G[l][m] q[m][col] on the matrix cores: 32 x 32 output tiles (rows l, columns
+        // col) dealt to the four wavefronts, k = m ascending in pairs (G's columns and q's rows beyond L are zero)
         {
-            const int hp = dp / 2 > 0 ? dp / 2 : 1;          // threads per row group: columns col and col + hp
-            const int col = tid % hp, g = tid / hp, NGR = 256 / hp;
-            const bool c0 = col < d, c1 = col + hp < d;
-            if (c0) {
-                for (int l0 = 8 * g; l0 < A.LP; l0 += 8 * NGR) {
-                    float acc0[8], acc1[8];
+            const int lane = tid & 63;
+            const int nMt = L > 32 ? 2 : 1, nNt = (d + 31) / 32;
+            const int LK = (L + 1) / 2 * 2;
+            for (int tile = wave; tile < nMt * nNt; tile += 4) {
+                const int I = tile / nNt, Jc = tile - I * nNt;
+                const int ra = min(32 * I + (lane & 31), A.LP - 1), cb = min(32 * Jc + (lane & 31), d - 1);
+                const float* pa = S + ra * A.SS + (lane >> 5);
+                const float* pb = q + (lane >> 5) * A.DS + cb;
+                att_f32x16 acc;
 #pragma unroll
-                    for (int x = 0; x < 8; ++x) acc0[x] = acc1[x] = 0.0f;
-                    for (int m = 0; m < L; ++m) {
-                        const float q0 = q[m * A.DS + col];
-                        const float q1 = c1 ? q[m * A.DS + col + hp] : 0.0f;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                for (int k = 0; k < LK; k += 2)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k * A.DS], acc, 0, 0, 0);
+                const int col = 32 * Jc + (lane & 31);
 #pragma unroll
-                        for (int x = 0; x < 8; ++x) {
-                            const float gv = (l0 + x < A.LP) ? S[(l0 + x) * A.SS + m] : 0.0f;
-                            acc0[x] = fmaf(gv, q0, acc0[x]);
-                            acc1[x] = fmaf(gv, q1, acc1[x]);
-                        }
-                    }
-#pragma unroll
-                    for (int x = 0; x < 8; ++x)
-                        if (l0 + x < L) {
-                            float* dst = dpre + (b * L + l0 + x) * d;
-                            dst[col] = q[(l0 + x) * A.DS + col] > 0.0f ? acc0[x] : 0.0f;
-                            if (c1) dst[col + hp] = q[(l0 + x) * A.DS + col + hp] > 0.0f ? acc1[x] : 0.0f;
-                        }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * I + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < L && col < d)
+                        dpre[(b * L + row) * d + col] = q[row * A.DS + col] > 0.0f ? acc[r] : 0.0f;
                 }
             }
         }
@@ -418,7 +414,7 @@ extern "C" int32_t dr_attn_pool_backward_f32(const float* pre, const float* v, c
     if (B == 0) return DR_OK;
     DR_REQUIRE(pre && v && s && gout && dpre && dv, "dr_attn_pool_backward_f32: NULL pointer");
     const int V = (d % 4 == 0 && (uintptr_t)pre % 16 == 0) ? 4 : ((d % 2 == 0 && (uintptr_t)pre % 8 == 0) ? 2 : 1);
-    const size_t lds = (size_t)att_layout(L, d).total * 4;
+    const size_t lds = (size_t)att_layout(L, d, true).total * 4;
     const float sd = (float)sqrt((double)d);
     hipStream_t st = (hipStream_t)stream;
     int grid = 0;
