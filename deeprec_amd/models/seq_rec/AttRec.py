@@ -48,7 +48,7 @@ class AttRec(SeqBase):
         self.alpha = 0.2
         print("AttSeqRec.")
 
-    def build_network(self, L, num_T, num_factor=150, num_neg=1, init=None):
+    def build_network(self, L, num_T, num_factor=150, num_neg=1, init=None, lazy_v=True):
         self.L, self.num_T, self.num_factor, self.num_neg = L, num_T, num_factor, num_neg
         dev, d = self.device, num_factor
         init = init or {}
@@ -72,8 +72,15 @@ class AttRec(SeqBase):
         self.linear_project = Wp.requires_grad_(True)
         self._timing = None
         self.optimizer = TFOptimizer("adagrad", self.learning_rate, initial_accumulator_value=0.05)
-        if self.shard is None:                       # the sharded lookups synchronise with the host (split sizes)
+        # hipGraph replay pays off while the step is launch-bound (the reference's B = 1000, L = 5: ~80 short launches);
+        # at C5 (B = 4096, L = 50) the kernels fill the GPU and the eager loop is faster (2.52 vs 2.69 ms).  The sharded
+        # lookups synchronise with the host (split sizes), so they are never captured.
+        if self.shard is None and self.batch_size * L * num_factor <= (1 << 22):
             self._step = GraphedStep(self.train_op)
+        else:
+            # V (AttRec.py:65) only appears in the L2 term and in getUserParam's return value: its dense pass is recorded
+            # and replayed when V is read (_common.Table.lazy); never under graph replay, which runs no host code
+            self.V.lazy = lazy_v
         return self
 
     def _seq_out(self, item_seq, want_weights=False):

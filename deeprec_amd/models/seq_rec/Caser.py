@@ -84,7 +84,7 @@ class Caser(SeqBase):
         self.neg_items = dict()
         print("Caser.")
 
-    def build_network(self, L, num_T, n_h=16, n_v=4, num_factor=150, num_neg=2, init=None):
+    def build_network(self, L, num_T, n_h=16, n_v=4, num_factor=150, num_neg=2, init=None, lazy_v=True):
         self.n_h, self.n_v, self.L, self.num_T, self.num_factor, self.num_neg = n_h, n_v, L, num_T, num_factor, num_neg
         dev, d = self.device, num_factor
         init = init or {}
@@ -99,6 +99,8 @@ class Caser(SeqBase):
             return Table(normal_(shape, 0.01, dev), sh)
         self.P, self.V = tab("P", (self.num_user, d)), tab("V", (self.num_user, d * L))
         self.Q, self.W, self.b = tab("Q", (self.num_item, d)), tab("W", (self.num_item, 2 * d)), tab("b", (self.num_item,))
+        # V is looked up by the reference (Caser.py:62) but its rows feed nothing: only the L2 term touches it
+        self.V.lazy = lazy_v
         dense = lambda n, shape, std: (to_dev(init[n], torch.float32, dev) if n in init else
                                        (normal_(shape, std, dev) if std else torch.zeros(shape, device=dev))).requires_grad_(True)
         self.conv_v_w, self.conv_v_b = dense("conv_v_w", (n_v, 1, L, 1), 1.0), dense("conv_v_b", (n_v,), 0)

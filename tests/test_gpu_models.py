@@ -615,3 +615,43 @@ def test_attrec_fused_attention_equals_library_graph(dev):
     np.testing.assert_allclose(wa, wb, rtol=1e-4, atol=1e-5 * np.abs(wb).max())
     np.testing.assert_allclose(ua[1].cpu().numpy(), ub[1].cpu().numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(ua[3].cpu().numpy(), ub[3].cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_lazy_dense_pass_of_unread_tables_is_exact(dev):
+    """_common.Table.lazy (Caser's / AttRec's V: in the L2 term only): the recorded dense optimizer passes, replayed when
+    the table is read, leave the table and its optimizer slots bit-identical to running them inside every step; nothing
+    else changes."""
+    from deeprec_amd.models.seq_rec.AttRec import AttRec
+    from deeprec_amd.models.seq_rec.Caser import Caser
+    rng = np.random.default_rng(11)
+    nu, ni, L, T_, B, d = 50, 70, 5, 3, 16, 12
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(torch.int32)
+    bs = [(t(rng.integers(0, nu, B)), t(rng.integers(1, ni, (B, L))), t(rng.integers(1, ni, (B, T_))),
+           t(rng.integers(1, ni, (B, T_)))) for _ in range(4)]
+
+    def run(cls, lazy, kw, init):
+        np.random.seed(123)                     # the tables / weights not in `init` draw their seeds from these
+        torch.manual_seed(123)
+        m = quiet(cls, None, nu, ni, 0.05 if cls is AttRec else 0.001, 0.01, 1, B)
+        quiet(m.build_network, L, T_, init=init, lazy_v=lazy, **kw)
+        if cls is AttRec:                       # small shapes replay a hipGraph (no host code per step): run eagerly here
+            m._step = None
+            m.V.lazy = lazy
+        for b in bs:
+            m.train_op(*b)
+        n_def = len(m.V._deferred)
+        out = {n: getattr(m, n).w.clone() for n in ("P", "V", "Q")}       # reading V.w replays the recorded passes
+        assert not m.V._deferred
+        out["V.slots"] = [x.clone() for x in m.optimizer.slots_for(m.V.w) if x is not None]
+        return out, n_def
+
+    for cls, kw in ((Caser, dict(num_factor=d, n_h=3, n_v=2, num_neg=1)), (AttRec, dict(num_factor=d, num_neg=1))):
+        init = {n: rng.normal(0, 0.05, (r, c)).astype(np.float32)
+                for n, r, c in (("P", nu, d), ("Q", ni, d), ("V", nu, d * L if cls is Caser else d))}
+        a, na = run(cls, True, kw, init)
+        b, nb = run(cls, False, kw, init)
+        assert na == len(bs) and nb == 0
+        for n in ("P", "V", "Q"):
+            assert torch.equal(a[n], b[n]), (cls.__name__, n)
+        for x, y in zip(a["V.slots"], b["V.slots"]):
+            assert torch.equal(x, y)
