@@ -569,6 +569,7 @@ def attn_pool_backward(pre, v, s, gout):
 
 # ------------------------------------------------------------------ Caser horizontal convolutions
 HC_MAX_L, HC_MAX_D, HC_MAX_C = 64, 256, 64
+HCONV_CHUNK_COLS = int(__import__("os").environ.get("DR_HCONV_CHUNK", "4096"))   # columns of G per library GEMM
 
 
 def hconv_rows(C, h):
@@ -576,7 +577,7 @@ def hconv_rows(C, h):
     return C * h * (h - 1) // 2
 
 
-def caser_hconv_forward(e, W, bias, C, chunk_cols=4096):
+def caser_hconv_forward(e, W, bias, C, chunk_cols=None):
     """Caser.py:132-154: e [B, L, d], W [C L (L+1) / 2, d], bias [C L] -> (out [B, C L], arg int32 [B, C L]).
     The products G = e W^T are library GEMMs over column chunks of whole heights (<= chunk_cols columns each)."""
     e = _req(e, torch.float32, "e", 3)
@@ -585,6 +586,8 @@ def caser_hconv_forward(e, W, bias, C, chunk_cols=4096):
     B, L, d = e.shape
     if W.shape != (hconv_rows(C, L + 1), d) or bias.numel() != C * L:
         raise ValueError("caser_hconv_forward: W must be [C L (L+1) / 2, d] and bias [C L]")
+    if chunk_cols is None:
+        chunk_cols = HCONV_CHUNK_COLS
     out = torch.empty((B, C * L), dtype=torch.float32, device=e.device)
     arg = torch.empty((B, C * L), dtype=torch.int32, device=e.device)
     e2 = e.reshape(B * L, d)
