@@ -234,7 +234,7 @@ class TFOptimizer:
         pend, table.pending = table.pending, []
         if (reg_mode == K.REG_DENSE and not pend and table.lazy and self._dev is None
                 and not (table._w.is_cuda and torch.cuda.is_current_stream_capturing())):
-            table._deferred.append((self, self.params(reg, K.REG_DENSE)))      # replayed when someone reads table.w
+            table.defer(self, self.params(reg, K.REG_DENSE))      # replayed when someone reads table.w
             return
         s0, s1 = self.slots_for(table.w)
         if reg_mode == K.REG_DENSE:
@@ -312,9 +312,22 @@ class Table:
     def flush(self):
         """Run the recorded dense passes of a lazy table (see __init__)."""
         todo, self._deferred = self._deferred, []
-        for opt, prm in todo:
+        for opt, prm, _, count in todo:
             s0, s1 = opt.slots_for(self._w)
-            K.dense_update(self._w, s0, s1, None, prm)
+            for _ in range(count):
+                K.dense_update(self._w, s0, s1, None, prm)
+
+    def defer(self, opt, prm):
+        """Record one dense pass; consecutive passes with identical parameters (Adagrad always; Adam once its bias
+        correction has converged in fp32) share one entry, so the record stays small over long runs."""
+        raw = bytes(prm)
+        if self._deferred and self._deferred[-1][0] is opt and self._deferred[-1][2] == raw:
+            self._deferred[-1][3] += 1
+        else:
+            self._deferred.append([opt, prm, raw, 1])
+
+    def deferred_passes(self):
+        return sum(e[3] for e in self._deferred)
 
     @property
     def k(self):

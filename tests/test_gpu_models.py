@@ -639,7 +639,7 @@ def test_lazy_dense_pass_of_unread_tables_is_exact(dev):
             m.V.lazy = lazy
         for b in bs:
             m.train_op(*b)
-        n_def = len(m.V._deferred)
+        n_def = m.V.deferred_passes()
         out = {n: getattr(m, n).w.clone() for n in ("P", "V", "Q")}       # reading V.w replays the recorded passes
         assert not m.V._deferred
         out["V.slots"] = [x.clone() for x in m.optimizer.slots_for(m.V.w) if x is not None]
