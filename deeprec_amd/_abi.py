@@ -35,6 +35,8 @@ SIGNATURES = {
     "dr_scatter_add_sorted_f32": (_i32, [_p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
     "dr_sparse_row_update_f32": (_i32, [_p, _p, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _optp, _p]),
     "dr_dense_update_f32": (_i32, [_p, _p, _p, _p, _i64, _optp, _p]),
+    "dr_dense_update_masked_f32": (_i32, [_p, _p, _p, _i64, _i32, _p, _optp, _p]),
+    "dr_mark_rows_u8": (_i32, [_p, _i64, _p, _i64, _i32, _p]),
     "dr_rownorm_clip_f32": (_i32, [_p, _i64, _i32, _f, _p]),
     "dr_pairwise_step_bytes": (_i64, [_i64, _i32, _i64, _i64, _i32]),
     "dr_bpr_step_f32": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _optp, _p, _p,

@@ -618,9 +618,11 @@ static int dispatch_seg(const SegArgs& a, int64_t n, hipStream_t st) {
 template <int KIND>
 __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ w, float* __restrict__ s0p,
                                                            float* __restrict__ s1p, const float* __restrict__ grad,
-                                                           int64_t count, OptP o) {
+                                                           int64_t count, OptP o, const uint8_t* __restrict__ skip,
+                                                           int k) {
     o = resolve(o);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        if (skip && skip[count <= 0xffffffffll ? (int64_t)((uint32_t)i / (uint32_t)k) : i / k]) continue;   // rows another kernel updates
         float wi = w[i];
         float g = grad ? grad[i] : 0.0f;
         if (o.reg_mode != DR_REG_NONE) g = g + o.reg * wi;
@@ -639,9 +641,13 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ w
 template <int KIND>
 __global__ __launch_bounds__(256) void dense_update4_kernel(float4* __restrict__ w, float4* __restrict__ s0p,
                                                             float4* __restrict__ s1p, const float4* __restrict__ grad,
-                                                            int64_t count4, OptP o) {
+                                                            int64_t count4, OptP o, const uint8_t* __restrict__ skip,
+                                                            int k4) {
     o = resolve(o);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (int64_t)gridDim.x * 256) {
+        // k % 4 == 0: a float4 never straddles two rows.  32-bit division where the index allows it (a 64-bit one is
+        // ~100 instructions on this pass of 4 loads and 3 stores)
+        if (skip && skip[count4 <= 0xffffffffll ? (int64_t)((uint32_t)i / (uint32_t)k4) : i / k4]) continue;
         const float4 w4 = w[i];
         float4 g4 = grad ? grad[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b4 = a4;
@@ -957,23 +963,23 @@ extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* s
                       (hipStream_t)stream, false, SegSel{0, 0, 0}, 0, nullptr, false);
 }
 
-extern "C" int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, const float* grad, int64_t count,
-                                       const dr_opt_params* opt, void* stream) {
-    DR_REQUIRE(count >= 0, "dr_dense_update_f32: negative count");
-    int rc = check_opt(opt, slot0, slot1, "dr_dense_update_f32");
+static int32_t dense_update_launch(const char* who, float* w, float* slot0, float* slot1, const float* grad,
+                                   int64_t count, const dr_opt_params* opt, const uint8_t* skip, int k, void* stream) {
+    DR_REQUIRE(count >= 0, "%s: negative count", who);
+    int rc = check_opt(opt, slot0, slot1, who);
     if (rc != DR_OK) return rc;
     if (count == 0) return DR_OK;
-    DR_REQUIRE(w != nullptr, "dr_dense_update_f32: w is NULL");
+    DR_REQUIRE(w != nullptr, "%s: w is NULL", who);
     OptP o = make_optp(opt);
     hipStream_t st = (hipStream_t)stream;
-    const bool v4 = count % 4 == 0 &&
+    const bool v4 = count % 4 == 0 && k % 4 == 0 &&
                     (((uintptr_t)w | (uintptr_t)slot0 | (uintptr_t)slot1 | (uintptr_t)grad) % 16 == 0);
     if (v4) {
         const int64_t c4 = count / 4;
         const int grid = grid_for(c4, 256, 2);
 #define DR_DU4(KIND_)                                                                                              \
     DR_LAUNCH((dense_update4_kernel<KIND_>), dim3(grid), dim3(256), 0, st, (float4*)w, (float4*)slot0, (float4*)slot1, \
-              (const float4*)grad, c4, o)
+              (const float4*)grad, c4, o, skip, k / 4)
         switch (opt->kind) {
             case DR_OPT_SGD: DR_DU4(DR_OPT_SGD); break;
             case DR_OPT_ADAM: DR_DU4(DR_OPT_ADAM); break;
@@ -981,29 +987,52 @@ extern "C" int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, con
             default: DR_DU4(DR_OPT_RMSPROP); break;
         }
 #undef DR_DU4
-        DR_CHECK_LAUNCH("dr_dense_update_f32");
+        DR_CHECK_LAUNCH(who);
         return DR_OK;
     }
-    int grid = grid_for(count, 256, 4);
+    const int grid = grid_for(count, 256, 4);
+#define DR_DU1(KIND_) \
+    DR_LAUNCH((dense_update_kernel<KIND_>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad, count, o, skip, k)
     switch (opt->kind) {
-        case DR_OPT_SGD:
-            DR_LAUNCH((dense_update_kernel<DR_OPT_SGD>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad,
-                               count, o);
-            break;
-        case DR_OPT_ADAM:
-            DR_LAUNCH((dense_update_kernel<DR_OPT_ADAM>), dim3(grid), dim3(256), 0, st, w, slot0, slot1, grad,
-                               count, o);
-            break;
-        case DR_OPT_ADAGRAD:
-            DR_LAUNCH((dense_update_kernel<DR_OPT_ADAGRAD>), dim3(grid), dim3(256), 0, st, w, slot0, slot1,
-                               grad, count, o);
-            break;
-        default:
-            DR_LAUNCH((dense_update_kernel<DR_OPT_RMSPROP>), dim3(grid), dim3(256), 0, st, w, slot0, slot1,
-                               grad, count, o);
-            break;
+        case DR_OPT_SGD: DR_DU1(DR_OPT_SGD); break;
+        case DR_OPT_ADAM: DR_DU1(DR_OPT_ADAM); break;
+        case DR_OPT_ADAGRAD: DR_DU1(DR_OPT_ADAGRAD); break;
+        default: DR_DU1(DR_OPT_RMSPROP); break;
     }
-    DR_CHECK_LAUNCH("dr_dense_update_f32");
+#undef DR_DU1
+    DR_CHECK_LAUNCH(who);
+    return DR_OK;
+}
+
+extern "C" int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, const float* grad, int64_t count,
+                                       const dr_opt_params* opt, void* stream) {
+    return dense_update_launch("dr_dense_update_f32", w, slot0, slot1, grad, count, opt, nullptr, 4, stream);
+}
+
+extern "C" int32_t dr_dense_update_masked_f32(float* table, float* slot0, float* slot1, int64_t rows, int32_t k,
+                                              const uint8_t* skip, const dr_opt_params* opt, void* stream) {
+    DR_REQUIRE(rows >= 0 && k >= 1, "dr_dense_update_masked_f32: bad sizes");
+    DR_REQUIRE(rows == 0 || skip != nullptr, "dr_dense_update_masked_f32: skip is NULL");
+    return dense_update_launch("dr_dense_update_masked_f32", table, slot0, slot1, nullptr, rows * (int64_t)k, opt, skip,
+                               (int)k, stream);
+}
+
+__global__ __launch_bounds__(256) void mark_rows_kernel(uint8_t* __restrict__ flags, int64_t rows,
+                                                        const int32_t* __restrict__ ids, int64_t n, uint8_t value) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = ids[e];
+        if (r >= 0 && r < rows) flags[r] = value;      // duplicates write the same byte
+    }
+}
+
+extern "C" int32_t dr_mark_rows_u8(uint8_t* flags, int64_t rows, const int32_t* ids, int64_t n, int32_t value,
+                                   void* stream) {
+    DR_REQUIRE(rows >= 0 && n >= 0, "dr_mark_rows_u8: bad sizes");
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(flags && ids, "dr_mark_rows_u8: NULL pointer");
+    DR_LAUNCH(mark_rows_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, flags, rows, ids, n,
+              (uint8_t)(value != 0));
+    DR_CHECK_LAUNCH("dr_mark_rows_u8");
     return DR_OK;
 }
 

@@ -312,6 +312,28 @@ def dense_update(w, slot0, slot1, grad, opt):
     return w
 
 
+def dense_update_masked(table, slot0, slot1, skip, opt):
+    """dr_dense_update_masked_f32: the dense-L2 optimizer pass over the rows with skip[row] == 0 (no gradient but reg*w)."""
+    table = _req(table, torch.float32, "table")
+    _slots(opt, slot0, slot1, table, "dense_update_masked")
+    rows = table.shape[0]
+    k = 1 if table.dim() == 1 else table.shape[1]
+    if _req(skip, torch.uint8, "skip", 1).numel() != rows:
+        raise ValueError("skip must hold one byte per table row")
+    check(_abi.lib().dr_dense_update_masked_f32(_ptr(table), _ptr(slot0), _ptr(slot1), rows, k, _ptr(skip), C.byref(opt),
+                                                _stream()), "dr_dense_update_masked_f32")
+    return table
+
+
+def mark_rows(flags, ids, value):
+    """flags[ids] = value (uint8 [rows]; ids int32, out-of-range ids ignored)."""
+    flags = _req(flags, torch.uint8, "flags", 1)
+    ids = _i32(ids, "ids")
+    check(_abi.lib().dr_mark_rows_u8(_ptr(flags), flags.numel(), _ptr(ids), ids.numel(), int(value), _stream()),
+          "dr_mark_rows_u8")
+    return flags
+
+
 def rownorm_clip(table, clip=1.0):
     table = _req(table, torch.float32, "table", 2)
     check(_abi.lib().dr_rownorm_clip_f32(_ptr(table), table.shape[0], table.shape[1], float(clip), _stream()),

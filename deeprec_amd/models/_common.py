@@ -169,6 +169,9 @@ class GraphedStep:
 # ----------------------------------------------------------------------------------------------
 # optimizer state with TensorFlow semantics ([TF-ext]; hyper-parameters cited in the model files)
 # ----------------------------------------------------------------------------------------------
+SPARSE_DENSE_MIN = 1 << 22     # elements: below this a table's dense-L2 step keeps the dense-gradient form
+
+
 class TFOptimizer:
     """kind: 'adam' (TF1 eps 1e-8 / Keras 1e-7), 'adagrad' (initial accumulator 0.1), 'rmsprop', 'sgd'."""
     KIND = {"sgd": K.OPT_SGD, "adam": K.OPT_ADAM, "adagrad": K.OPT_ADAGRAD, "rmsprop": K.OPT_RMSPROP}
@@ -242,6 +245,17 @@ class TFOptimizer:
                 # no lookup this step (AttRec's V): the gradient is reg * w alone -- no zero-filled dense gradient to
                 # write and read back (the kernel computes 0 + reg * w either way, so the result is bit-identical)
                 K.dense_update(table.w, s0, s1, None, self.params(reg, K.REG_DENSE))
+                return
+            if len(pend) == 1 and table.w.numel() >= SPARSE_DENSE_MIN:
+                # one lookup of a big table: the rows it touched get sum + reg*w from the sparse kernel, every other
+                # row reg*w from a dense pass that skips them -- no zero-filled dense gradient to write, scatter into
+                # and read back (bit-identical: the dense path computes (0 + sum) + reg*w for the same rows)
+                ids, rows = pend[0]
+                flags = table.row_flags()
+                K.mark_rows(flags, ids, 1)
+                K.dense_update_masked(table.w, s0, s1, flags, self.params(reg, K.REG_DENSE))
+                K.sparse_row_update(table.w, s0, s1, ids, rows, self.params(reg, K.REG_TOUCHED))
+                K.mark_rows(flags, ids, 0)
                 return
             G = table.dense_grad()
             for ids, rows in pend:
@@ -332,6 +346,12 @@ class Table:
     @property
     def k(self):
         return 1 if self._w.dim() == 1 else self._w.shape[1]
+
+    def row_flags(self):
+        """uint8 [rows], all zero between steps (TFOptimizer.apply_table marks the looked-up rows while it runs)."""
+        if getattr(self, "_flags", None) is None:
+            self._flags = torch.zeros(self._w.shape[0], dtype=torch.uint8, device=self._w.device)
+        return self._flags
 
     def dense_grad(self):
         if self._g is None:

@@ -98,17 +98,19 @@ class AttRec(SeqBase):
         w = torch.softmax(logits, -1) * (1 - eye)
         return (w @ v).mean(1), w
 
-    def _distance(self, out, user_id, item_id):
-        """AttRec.py:190-232 -> [B, n]."""
+    def _distance(self, out, user_id, item_id, u=None):
+        """AttRec.py:190-232 -> [B, n].  u: the users' P rows when the caller has looked them up already (the train graph
+        uses them for the target and the negative distance: one lookup, one gradient list)."""
         w_items, w_items_2 = self.X.lookup(item_id), self.Q.lookup(item_id)
-        u = self.P.lookup(user_id)[:, None, :]
+        u = (self.P.lookup(user_id) if u is None else u)[:, None, :]
         return self.alpha * ((w_items - u) ** 2).sum(2) + (1 - self.alpha) * ((out[:, None, :] - w_items_2) ** 2).sum(2)
 
     def train_op(self, user_id, item_seq, item_id, neg_item_id):
         self.linear_project.grad = None
         out, _ = self._seq_out(item_seq)
-        target = self._distance(out, user_id, item_id)
-        negative = self._distance(out, user_id, neg_item_id)
+        u = self.P.lookup(user_id)
+        target = self._distance(out, user_id, item_id, u)
+        negative = self._distance(out, user_id, neg_item_id, u)
         loss = torch.clamp(target - negative + 0.5, min=0).sum()
         loss.backward()
         if self.shard:

@@ -131,6 +131,14 @@ int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* slot1, int64
  * gradient dense) and the small dense weights of NeuMF/NFM/NNMF/AttRec/Caser. */
 int32_t dr_dense_update_f32(float* w, float* slot0, float* slot1, const float* grad, int64_t count,
                             const dr_opt_params* opt, void* stream);
+/* The dense (DR_REG_DENSE) step of a table whose gradient is sparse, without a dense gradient tensor: rows with
+ * skip[row] != 0 are left alone (dr_sparse_row_update_f32 with DR_REG_TOUCHED gives them sum + reg*w, the same
+ * expression), every other row gets g = 0 + reg*w.  dr_mark_rows_u8 sets flags[ids[e]] = (value != 0) for the valid ids
+ * (set before, clear after: the flag array stays all zero between steps).  Replaces zero-fill + scatter-add + a pass
+ * that reads the dense gradient ([TF-ext] the reference's densified IndexedSlices + reg*l2_loss gradient). */
+int32_t dr_dense_update_masked_f32(float* table, float* slot0, float* slot1, int64_t rows, int32_t k,
+                                   const uint8_t* skip, const dr_opt_params* opt, void* stream);
+int32_t dr_mark_rows_u8(uint8_t* flags, int64_t rows, const int32_t* ids, int64_t n, int32_t value, void* stream);
 
 /* cml.py:80-81  tf.clip_by_norm(table, clip, axes=[1]) applied in place. */
 int32_t dr_rownorm_clip_f32(float* table, int64_t rows, int32_t k, float clip, void* stream);

@@ -655,3 +655,41 @@ def test_lazy_dense_pass_of_unread_tables_is_exact(dev):
             assert torch.equal(a[n], b[n]), (cls.__name__, n)
         for x, y in zip(a["V.slots"], b["V.slots"]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adam", "adagrad", "rmsprop"])
+def test_dense_l2_step_without_dense_gradient_is_exact(dev, kind):
+    """TFOptimizer.apply_table in DR_REG_DENSE mode for a big table with one lookup: dr_mark_rows_u8 +
+    dr_dense_update_masked_f32 + dr_sparse_row_update_f32 (touched rows) against the dense-gradient form (zero fill +
+    dr_scatter_add_sorted_f32 + dr_dense_update_f32): table and optimizer slots bit-identical after three steps, with
+    duplicate ids and an id out of range; the flag array is all zero again afterwards."""
+    from deeprec_amd import kernels as K
+    from deeprec_amd.models import _common as C
+    rng = np.random.default_rng(17)
+    R, k, n = 5000, 32, 3000
+    w0 = rng.normal(0, 0.1, (R, k)).astype(np.float32)
+    steps = []
+    for _ in range(3):
+        ids = rng.integers(0, R // 4, n).astype(np.int32)          # heavy duplication
+        ids[5] = R + 7                                             # out of range: skipped by both forms
+        steps.append((torch.from_numpy(ids).to(dev), torch.from_numpy(rng.normal(0, 1, (n, k)).astype(np.float32)).to(dev)))
+
+    def run(min_elems):
+        old = C.SPARSE_DENSE_MIN
+        C.SPARSE_DENSE_MIN = min_elems
+        try:
+            t = C.Table(torch.from_numpy(w0).to(dev))
+            o = C.TFOptimizer(kind, 0.01)
+            for ids, rows in steps:
+                t.pending.append((ids, rows))
+                o.begin_step()
+                o.apply_table(t, 0.05, K.REG_DENSE)
+            return t, [x.clone() for x in o.slots_for(t.w) if x is not None]
+        finally:
+            C.SPARSE_DENSE_MIN = old
+    a, sa = run(1)
+    b, sb = run(1 << 60)
+    assert torch.equal(a.w, b.w)
+    for x, y in zip(sa, sb):
+        assert torch.equal(x, y)
+    assert int(a.row_flags().sum()) == 0 and getattr(b, "_flags", None) is None
