@@ -44,6 +44,7 @@ SIGNATURES = {
     "dr_bpr_plan_f32": (_i32, [_i64, _i64, _i32, _p, _p, _p, _i64, _i32, _p, _i64, _p]),
     "dr_bpr_step_planned_f32": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _optp, _p, _p,
                                        _i64, _p]),
+    "dr_bpr_step_static_f32": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _optp, _p, _p]),
     "dr_bpr_forward_f32": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p]),
     "dr_pointwise_forward_f32": (_i32, [_p, _p, _p, _p, _f, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _p,
                                         _p, _p, _p]),

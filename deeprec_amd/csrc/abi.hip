@@ -2,6 +2,7 @@
 #include "dr_common.h"
 
 namespace dr {
+thread_local bool g_no_side_streams = false;
 char* last_error_buf() {
     static thread_local char buf[512] = {0};
     return buf;

@@ -61,6 +61,10 @@ bool prof_slot(const char* name, hipEvent_t* e0, hipEvent_t* e1);
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                    \
     } while (0)
 
+// Set (per host thread) while an entry point that must not create HIP objects is running (dr_bpr_step_static_f32):
+// the helper-stream providers then hand back the caller's stream.  Defined in abi.hip.
+extern thread_local bool g_no_side_streams;
+
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // Memory-bound launches: cap the grid at CUs * blocks-per-CU and grid-stride the rest

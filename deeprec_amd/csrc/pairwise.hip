@@ -385,7 +385,7 @@ struct SideStream {
 static SideStream* side_stream() {
     static thread_local SideStream side[32];
     static const bool off = getenv("DR_NO_OVERLAP") != nullptr;
-    if (off) return nullptr;
+    if (off || g_no_side_streams) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
     SideStream& x = side[dev];
@@ -840,6 +840,60 @@ extern "C" int32_t dr_bpr_step_planned_f32(float* P, float* Pslot0, float* Pslot
                                            float* loss_out, void* ws, int64_t ws_bytes, void* stream) {
     return bpr_step_impl(P, Pslot0, Pslot1, num_user, Q, Qslot0, Qslot1, num_item, k, u, i, j, B, opt, 0, loss_out, ws,
                          ws_bytes, stream, 2);
+}
+
+// ---- dr_bpr_step_static_f32: dr_bpr_step_f32 for callers that cannot allocate ------------------------------------
+// The step's workspace (g, per-sample loss, stash rows, id / coefficient lists, the combined segment plan with its
+// block partials) lives in a file-scope device array instead of a caller-provided buffer.  `scratch` below is the
+// HOST-side stand-in of that array: its device address is looked up once per device with hipGetSymbolAddress and
+// only that pointer is ever handed to kernels.  Every GPU holds its own copy until the process ends.
+#define DR_STATIC_WS_BYTES (4ll << 20)
+static __device__ __align__(256) unsigned char scratch[DR_STATIC_WS_BYTES];
+
+namespace dr {
+static void* g_scratch_ptr[32] = {nullptr};
+// device address of this device's `scratch`; looked up on the first call on each device (the library has no init call)
+static int static_scratch(void** out) {
+    int dev = -1;
+    DR_HIP(hipGetDevice(&dev));
+    DR_REQUIRE(dev >= 0 && dev < 32, "dr_bpr_step_static_f32: device index %d out of range", dev);
+    void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        DR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        DR_REQUIRE(p != nullptr && ((uintptr_t)p % 256 == 0), "dr_bpr_step_static_f32: bad scratch address");
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);  // racing threads store the same address
+    }
+    *out = p;
+    return DR_OK;
+}
+}  // namespace dr
+
+extern "C" int32_t dr_bpr_step_static_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q,
+                                          float* Qslot0, float* Qslot1, int64_t num_item, int32_t k, const int32_t* u,
+                                          const int32_t* i, const int32_t* j, int64_t B, const dr_opt_params* opt,
+                                          float* loss_out, void* stream) {
+    DR_REQUIRE(B >= 0 && B <= DR_STATIC_MAX_B, "dr_bpr_step_static_f32: B=%lld exceeds the static maximum %d",
+               (long long)B, DR_STATIC_MAX_B);
+    DR_REQUIRE(k >= 1 && k <= DR_STATIC_MAX_K, "dr_bpr_step_static_f32: k=%d exceeds the static maximum %d", k,
+               DR_STATIC_MAX_K);
+    DR_REQUIRE(opt != nullptr && opt->reg_mode != DR_REG_DENSE,
+               "dr_bpr_step_static_f32: DR_REG_DENSE needs table-sized dense gradients; use dr_bpr_step_f32");
+    StepLayout L;
+    if (step_layout(B, k, 2 * B, num_user, num_item, false, &L) != 0) return DR_ERR_LAUNCH;
+    if (L.total > DR_STATIC_WS_BYTES)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_bpr_step_static_f32: step needs %lld bytes, static scratch holds %lld",
+                (long long)L.total, (long long)DR_STATIC_WS_BYTES);
+    void* ws = nullptr;
+    int rc = static_scratch(&ws);
+    if (rc != DR_OK) return rc;
+    // 3B <= 4096 keys: the plan is ONE workgroup (plan_small_kernel), no device-wide sort; no helper streams or events
+    // are created or used (g_no_side_streams), nothing is allocated or freed.  The plan kernels write every header field
+    // and every partial row before it is read, so the previous call's contents need no clearing.
+    g_no_side_streams = true;
+    rc = bpr_step_impl(P, Pslot0, Pslot1, num_user, Q, Qslot0, Qslot1, num_item, k, u, i, j, B, opt, 0, loss_out, ws,
+                       DR_STATIC_WS_BYTES, stream, 0);
+    g_no_side_streams = false;
+    return rc;
 }
 
 extern "C" int32_t dr_pointwise_forward_f32(const float* P, const float* Q, const float* BU, const float* BI, float mu,

@@ -321,7 +321,7 @@ hipStream_t seg_side_stream(hipStream_t main, hipEvent_t* fork, hipEvent_t* join
     static const bool off = getenv("DR_NO_OVERLAP") != nullptr;
     static const bool always = getenv("DR_OVERLAP") != nullptr;
     int dev = 0;
-    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return main;
+    if (off || g_no_side_streams || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return main;
     if (!always) {
         // Launched eagerly the fork / join costs four event calls (~45 us of host time per fused step, measured)
         // and buys no GPU time; as a parallel branch of a captured graph it is free on the host and worth ~5 %.

@@ -399,6 +399,25 @@ def bpr_step(P, Q, slotsP, slotsQ, u, i, j, opt, ws=None, planned=False):
     return ws.loss
 
 
+STATIC_MAX_B, STATIC_MAX_K = 1024, 128
+
+
+def bpr_step_static(P, Q, slotsP, slotsQ, u, i, j, opt, loss_out):
+    """dr_bpr_step_static_f32: bpr_step() whose workspace is the library's own file-scope device array -- the call
+    allocates nothing (loss_out: caller's float32 [1] tensor).  B <= 1024, k <= 128, no DR_REG_DENSE; calls that
+    overlap on one GPU race (include/deeprec_amd.h)."""
+    B = _check_pq(P, Q, u, (("u", u), ("i", i), ("j", j)))
+    _slots(opt, slotsP[0], slotsP[1], P, "bpr_step_static(P)")
+    _slots(opt, slotsQ[0], slotsQ[1], Q, "bpr_step_static(Q)")
+    if _req(loss_out, torch.float32, "loss_out").numel() < 1:
+        raise ValueError("loss_out must hold one float")
+    check(_abi.lib().dr_bpr_step_static_f32(_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), P.shape[0], _ptr(Q),
+                                            _ptr(slotsQ[0]), _ptr(slotsQ[1]), Q.shape[0], P.shape[1], _ptr(u), _ptr(i),
+                                            _ptr(j), B, C.byref(opt), _ptr(loss_out), _stream()),
+          "dr_bpr_step_static_f32")
+    return loss_out
+
+
 def bpr_forward(P, Q, u, i, j):
     B = _check_pq(P, Q, u, (("u", u), ("i", i), ("j", j)))
     g = torch.empty(B, dtype=torch.float32, device=P.device)

@@ -173,6 +173,21 @@ int32_t dr_bpr_step_planned_f32(float* P, float* Pslot0, float* Pslot1, int64_t 
                                 const dr_opt_params* opt, float* loss_out, void* ws, int64_t ws_bytes,
                                 void* stream);
 
+/* dr_bpr_step_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight serving /
+ * online-update loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arithmetic, same
+ * results bit for bit as dr_bpr_step_f32, but the step's workspace is a file-scope device array inside the library
+ * (4 MiB per GPU, held until the process ends) instead of a caller buffer, and the call allocates / frees nothing
+ * and creates no streams or events.  Limits: B <= DR_STATIC_MAX_B, k <= DR_STATIC_MAX_K, opt->reg_mode !=
+ * DR_REG_DENSE (that mode needs table-sized dense gradients); anything beyond is DR_ERR_ARG / DR_ERR_WORKSPACE with
+ * a message.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads)
+ * race -- serialise them.  The array keeps the last call's contents; every field is rewritten before it is read. */
+#define DR_STATIC_MAX_B 1024 /* the reference's BPRMF batch size (bprmf.py:41) */
+#define DR_STATIC_MAX_K 128
+int32_t dr_bpr_step_static_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q,
+                               float* Qslot0, float* Qslot1, int64_t num_item, int32_t k,
+                               const int32_t* u, const int32_t* i, const int32_t* j, int64_t B,
+                               const dr_opt_params* opt, float* loss_out, void* stream);
+
 /* Forward only: x_ui - x_uj and -log(sigmoid) per sample (bprmf.py:84-92,118-119). */
 int32_t dr_bpr_forward_f32(const float* P, const float* Q, int64_t num_user, int64_t num_item,
                            int32_t k, const int32_t* u, const int32_t* i, const int32_t* j,
