@@ -58,6 +58,9 @@ SIGNATURES = {
     "dr_score_topk_bytes": (_i64, [_i64, _i64, _i32, _i32, _i64, _i32]),
     "dr_score_topk_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _p, _p, _p, _p, _i64, _i32,
                                  _p, _p, _p, _p, _i64, _p]),
+    "dr_score_rank_exact_bytes": (_i64, [_i64, _i64, _i32, _i64, _i32]),
+    "dr_score_rank_exact_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _f, _p, _p, _p, _p, _i64, _p, _p,
+                                       _i64, _p]),
     "dr_topk_rank_f32": (_i32, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "dr_score_matrix_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _i32, _p, _p, _i64, _p]),
     "dr_init_normal_f32": (_i32, [_p, _i64, C.c_uint64, _f, C.c_uint64, _p]),

@@ -52,6 +52,13 @@ struct ScoreArgs {
     int32_t* part_i;     // [S, Nu, K]
     float* out;          // [Nu, Ni] (matrix mode)
     const int32_t* mode_flag;  // device word: 0 = every user has <= 1 held-out item (score_kernel_t1 runs), 1 = general
+    // BAND kernels (dr_score_rank_exact_f32): tgt_score[x] / tgt_hi[x] = the held-out item's reference-order score
+    // minus / plus a bound on |MFMA score - reference-order score|.  A candidate above the band counts, one below
+    // does not, one inside is appended to band_list as (user row, target slot, item) for the exact re-score.
+    const float* tgt_hi;
+    int32_t* band_list;
+    int32_t* band_count;       // [0] entries appended (may exceed band_cap: then the list overflowed)
+    int band_cap;
 };
 
 __device__ __forceinline__ float score_epilogue(float acc, float cdot, const float* uadd, const float* iadd, int64_t u,
@@ -77,7 +84,8 @@ constexpr int TPTR_OFF = SS_OFF + TU * LDS_S;     // [TU+1] panel-local target o
 constexpr int TSC_OFF = TPTR_OFF + TU + 2;        // [TCAP] target scores
 constexpr int TID_OFF = TSC_OFF + TCAP;           // [TCAP] target item id, -1 = masked target
 constexpr int TCNT_OFF = TID_OFF + TCAP;          // [TCAP] rank counters
-constexpr int TOPV_OFF = TCNT_OFF + TCAP + 2;     // [TU][K] scores, then [TU][K] item ids
+constexpr int THI_OFF = TCNT_OFF + TCAP;          // [TCAP] upper end of the target's band (BAND kernels only)
+constexpr int TOPV_OFF = THI_OFF + TCAP + 2;      // [TU][K] scores, then [TU][K] item ids
 static_assert((SS_OFF % 4) == 0 && (TOPV_OFF % 4) == 0, "LDS alignment");
 
 struct Sel {
@@ -91,6 +99,7 @@ struct Sel {
     __device__ __forceinline__ float* tsc() const { return base + TSC_OFF; }
     __device__ __forceinline__ int* tidl() const { return (int*)(base + TID_OFF); }
     __device__ __forceinline__ int* tcnt() const { return (int*)(base + TCNT_OFF); }
+    __device__ __forceinline__ float* thi() const { return base + THI_OFF; }
     __device__ __forceinline__ float* topv() const { return base + TOPV_OFF; }
     __device__ __forceinline__ int* topi(int K) const { return (int*)(base + TOPV_OFF + TU * K); }
 };
@@ -152,6 +161,7 @@ __device__ __forceinline__ void sel_init(Sel& z, const ScoreArgs& a, int64_t u0,
                 z.tsc()[x] = a.tgt_score[z.tg0 + x];
                 z.tidl()[x] = a.tgt_masked[z.tg0 + x] ? -1 : a.tgt_idx[z.tg0 + x];
                 z.tcnt()[x] = 0;
+                if (a.tgt_hi) z.thi()[x] = a.tgt_hi[z.tg0 + x];
             }
     }
 }
@@ -195,7 +205,7 @@ __device__ __forceinline__ void sel_store_scores(const Sel& z, const ScoreArgs& 
 // Common case first: no masked item in this quarter and a full tile -> one group maximum against the K-th
 // best, and a plain count of scores above the target (ties and masked / ragged quarters take the exact
 // per-score path).  Must be called by whole waves (DPP).
-template <bool MATRIX, bool TG_LDS>
+template <bool MATRIX, bool TG_LDS, bool BAND>
 __device__ __forceinline__ void sel_tile_impl(Sel& z, const ScoreArgs& a, int64_t u0, int64_t i0, int th) {
     if (MATRIX) {
         for (int e = th; e < TU * TI; e += 256) {
@@ -270,12 +280,40 @@ __device__ __forceinline__ void sel_tile_impl(Sel& z, const ScoreArgs& a, int64_
         const float st = TG_LDS ? z.tsc()[x] : a.tgt_score[z.tg0 + x];
         int cnt = 0;
         bool tie = false;
+        if (BAND) {
+            // st = lower end of the band, hi = upper end: above counts, inside goes to the exact re-score
+            const float hi = TG_LDS ? z.thi()[x] : a.tgt_hi[z.tg0 + x];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                cnt += (sv[c] > hi) ? 1 : 0;
+                tie |= (sv[c] >= st) && (sv[c] <= hi);
+            }
+            if (tie || !plain) {
+                const int item0 = (int)i0 + q * 16;
+                cnt = 0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (!((live >> c) & 1u)) continue;
+                    if (sv[c] > hi) {
+                        ++cnt;
+                    } else if (sv[c] >= st && item0 + c != ct) {
+                        const int p = atomicAdd(a.band_count, 1);
+                        if (p < a.band_cap) {
+                            a.band_list[3 * (int64_t)p] = (int32_t)(u0 + row);
+                            a.band_list[3 * (int64_t)p + 1] = z.tg0 + x;
+                            a.band_list[3 * (int64_t)p + 2] = item0 + c;
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             cnt += (sv[c] > st) ? 1 : 0;
             tie |= (sv[c] == st);
         }
-        if (tie || !plain) {
+        }
+        if (!BAND && (tie || !plain)) {
             const int item0 = (int)i0 + q * 16;
             cnt = 0;
 #pragma unroll
@@ -320,10 +358,10 @@ __device__ __forceinline__ void sel_tile_impl(Sel& z, const ScoreArgs& a, int64_
 
 // two instantiations, so that the usual one (targets cached in LDS) has no global access in its target loop:
 // a wait on one would also wait for the item-tile prefetch in flight
-template <bool MATRIX>
+template <bool MATRIX, bool BAND = false>
 __device__ __forceinline__ void sel_tile(Sel& z, const ScoreArgs& a, int64_t u0, int64_t i0, int th) {
-    if (MATRIX || z.tg_lds) sel_tile_impl<MATRIX, true>(z, a, u0, i0, th);
-    else sel_tile_impl<MATRIX, false>(z, a, u0, i0, th);
+    if (MATRIX || z.tg_lds) sel_tile_impl<MATRIX, true, BAND && !MATRIX>(z, a, u0, i0, th);
+    else sel_tile_impl<MATRIX, false, BAND && !MATRIX>(z, a, u0, i0, th);
 }
 
 // a barrier must precede (top-K lists and counters are written by other threads of the group)
@@ -367,7 +405,7 @@ __device__ __forceinline__ void stage_chunk(float* __restrict__ dst, const float
 }
 
 // ---- any k: user panel and item tile both staged through LDS in k-chunks (one block per CU) -----------
-template <bool MATRIX>
+template <bool MATRIX, bool BAND = false>
 __global__ __launch_bounds__(256) void score_kernel_anyk(ScoreArgs a) {
     extern __shared__ __align__(16) float smem[];
     float* sU = smem;                // [TU][LDK]
@@ -413,7 +451,7 @@ __global__ __launch_bounds__(256) void score_kernel_anyk(ScoreArgs a) {
         }
         sel_store_scores(z, a, acc, ua, load_iadd(a, i0 + wi * 32 + (lane & 31)), affine, wu, wi, lane);
         __syncthreads();
-        sel_tile<MATRIX>(z, a, u0, i0, tid);  // the next write of sS is two barriers away
+        sel_tile<MATRIX, BAND>(z, a, u0, i0, tid);  // the next write of sS is two barriers away
     }
     if (!MATRIX) {
         __syncthreads();
@@ -539,7 +577,7 @@ __device__ __forceinline__ void load_areg(float (&areg)[KS], const ScoreArgs& a,
 // one block's MFMA stream covers the other's staging and selection stalls.  fp32 MFMA shares the SIMD's vector
 // pipe with ordinary VALU work (measured: a barrier-locked two-group ping-pong form ran no faster), so what
 // counts is the number of non-MFMA instructions per tile.
-template <bool MATRIX, int KS, bool VEC>
+template <bool MATRIX, int KS, bool VEC, bool BAND = false>
 __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
     using G = Geo<KS, VEC>;
     extern __shared__ __align__(16) float smem[];
@@ -615,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
         }
         sel_store_scores(z, a, acc, ua, ia, affine, wu, wi, lane);
         __syncthreads();
-        sel_tile<MATRIX>(z, a, u0, i0, tid);  // the next write of sS is two barriers away
+        sel_tile<MATRIX, BAND>(z, a, u0, i0, tid);  // the next write of sS is two barriers away
     }
     if (!MATRIX) {
         __syncthreads();
@@ -1141,12 +1179,12 @@ static size_t score_smem_bytes(int K, bool anyk) {
     return ((anyk ? (size_t)2 * TI * LDK : (size_t)TI * LDP) + sel_area_floats(K)) * 4;
 }
 
-template <bool MATRIX, int KS, bool VEC>
+template <bool MATRIX, int KS, bool VEC, bool BAND = false>
 static int launch_score_regs(const ScoreArgs& a, dim3 grid, hipStream_t st) {
     const size_t smem = score_smem_bytes(a.K, false);
-    DR_HIP(hipFuncSetAttribute((const void*)score_kernel<MATRIX, KS, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
-    DR_LAUNCH((score_kernel<MATRIX, KS, VEC>), grid, dim3(256), smem, st, a);
+    DR_HIP(hipFuncSetAttribute((const void*)score_kernel<MATRIX, KS, VEC, BAND>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DR_LAUNCH((score_kernel<MATRIX, KS, VEC, BAND>), grid, dim3(256), smem, st, a);
     DR_CHECK_LAUNCH("score_kernel");
     return DR_OK;
 }
@@ -1181,9 +1219,22 @@ static int launch_score(const ScoreArgs& a, dim3 grid, hipStream_t st) {
     return DR_OK;
 }
 
+// the BAND form of launch_score<false> (dr_score_rank_exact_f32)
+static int launch_score_band(const ScoreArgs& a, dim3 grid, hipStream_t st) {
+    const bool vec = (a.k & 7) == 0;
+    if (a.k <= 64) return vec ? launch_score_regs<false, 32, true, true>(a, grid, st) : launch_score_regs<false, 32, false, true>(a, grid, st);
+    if (a.k <= 128) return vec ? launch_score_regs<false, 64, true, true>(a, grid, st) : launch_score_regs<false, 64, false, true>(a, grid, st);
+    if (a.k <= 256) return vec ? launch_score_regs<false, 128, true, true>(a, grid, st) : launch_score_regs<false, 128, false, true>(a, grid, st);
+    const size_t smem = score_smem_bytes(a.K, true);
+    DR_HIP(hipFuncSetAttribute((const void*)score_kernel_anyk<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DR_LAUNCH((score_kernel_anyk<false, true>), grid, dim3(256), smem, st, a);
+    DR_CHECK_LAUNCH("score_kernel_anyk");
+    return DR_OK;
+}
+
 // Prepare (U', I', uadd, iadd, cdot) for a score kind.  Returns DR_OK / error.
 static int prepare_operands(const float* U, const float* U2, int64_t Nu, const float* I, const float* I2,
-                            const float* item_bias, int64_t Ni, int k, int kind, float alpha, char* base,
+                            const float* item_bias, int64_t Ni, int k, int kind, float w1, float w2, char* base,
                             const TopkLayout& L, hipStream_t st, ScoreArgs* a) {
     a->U = U;
     a->I = I;
@@ -1199,7 +1250,6 @@ static int prepare_operands(const float* U, const float* U2, int64_t Nu, const f
         if (Nu > 0) DR_LAUNCH(neg_sqnorm_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, U, (const float*)nullptr, Nu, k, 1.0f, 0.0f, uadd);
         if (Ni > 0) DR_LAUNCH(neg_sqnorm_kernel, dim3(grid_for(Ni, 256)), dim3(256), 0, st, I, (const float*)nullptr, Ni, k, 1.0f, 0.0f, iadd);
     } else {
-        const float w1 = alpha, w2 = 1.0f - alpha;
         float* ucat = (float*)(base + L.ucat);
         float* icat = (float*)(base + L.icat);
         if (Nu > 0) {
@@ -1220,6 +1270,256 @@ static int prepare_operands(const float* U, const float* U2, int64_t Nu, const f
     a->iadd = iadd;
     DR_CHECK_LAUNCH("score operand preparation");
     return DR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dr_score_rank_exact_f32: ranks in the REFERENCE's float32 operation order (numpy), SURVEY H2.
+// The reference evaluators score in numpy: direct squared differences, np.sum over the last axis
+// (SeqRecMetrics.py:122-123) -- numpy's pairwise summation, restated below -- while the MFMA pass computes the
+// expanded form as fmaf chains.  The two differ in the last bits, so near-ties could order differently.  Here the
+// MFMA pass only decides what is certain: a candidate whose MFMA score lies outside [s_t - delta, s_t + delta]
+// (s_t = the held-out item's reference-order score, delta = a bound on |MFMA score - reference-order score|) is
+// counted or not; the few inside are re-scored in the reference's order and compared exactly.
+// ---------------------------------------------------------------------------------------------------------------
+
+// numpy's float32 pairwise summation (numpy/_core/src/umath/loops_utils.h.src, *_pairwise_sum): n < 8 sequential from
+// 0; n <= 128: eight strided accumulators, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 rest; above: split at
+// n/2 rounded down to a multiple of 8.  term(c) = the c-th float32 summand.  Checked against numpy in
+// tests/test_golden_cpu.py through the same restatement in oracle/ref_ops.py.
+template <class Term>
+__device__ __forceinline__ float np_block_sum(const Term& term, int lo, int n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (int c = 0; c < n; ++c) res = res + term(lo + c);
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = term(lo + q);
+    int c = 8;
+    for (; c < n - (n % 8); c += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = r[q] + term(lo + c + q);
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; c < n; ++c) res = res + term(lo + c);
+    return res;
+}
+template <class Term>
+__device__ __forceinline__ float np_pairwise_sum(const Term& term, int n) {
+    if (n <= 128) return np_block_sum(term, 0, n);
+    // post-order walk of numpy's recursion with an explicit stack (n <= 128 * 2^7)
+    int lo_s[8], n_s[8], stage[8];
+    float left[8];
+    int sp = 0;
+    lo_s[0] = 0; n_s[0] = n; stage[0] = 0; left[0] = 0.0f;
+    float ret = 0.0f;
+    while (sp >= 0) {
+        if (stage[sp] == 0) {
+            if (n_s[sp] <= 128) {
+                ret = np_block_sum(term, lo_s[sp], n_s[sp]);
+                --sp;
+            } else {
+                int n2 = n_s[sp] / 2;
+                n2 -= n2 % 8;
+                stage[sp] = 1;
+                lo_s[sp + 1] = lo_s[sp]; n_s[sp + 1] = n2; stage[sp + 1] = 0;
+                ++sp;
+            }
+        } else if (stage[sp] == 1) {
+            left[sp] = ret;
+            int n2 = n_s[sp] / 2;
+            n2 -= n2 % 8;
+            stage[sp] = 2;
+            lo_s[sp + 1] = lo_s[sp] + n2; n_s[sp + 1] = n_s[sp] - n2; stage[sp + 1] = 0;
+            ++sp;
+        } else {
+            ret = left[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+struct ExactArgs {
+    const float* U; const float* U2; const float* I; const float* I2; const float* bias;
+    int64_t Nu, Ni;
+    int k, kind;
+    float w1, w2;
+};
+
+// the reference's float32 arithmetic for one (user row, item) pair:
+//   DR_SCORE_DOT         (p * q).sum()                         [+ bias]   (the evaluators' predict stand-in)
+//   DR_SCORE_NEG_SQDIST  -((p - q) ** 2).sum()
+//   DR_SCORE_TWO_DIST    (-w1) * ((p - X) ** 2).sum() - w2 * ((s - Q) ** 2).sum()   (SeqRecMetrics.py:122-123)
+__device__ __forceinline__ float ref_order_score(const ExactArgs& e, int64_t u, int64_t it) {
+    const float* pu = e.U + u * e.k;
+    const float* pi = e.I + it * e.k;
+    float s;
+    if (e.kind == DR_SCORE_DOT) {
+        s = np_pairwise_sum([&](int c) { return pu[c] * pi[c]; }, e.k);
+    } else {
+        const float d1 = np_pairwise_sum([&](int c) { const float d = pu[c] - pi[c]; return d * d; }, e.k);
+        if (e.kind == DR_SCORE_NEG_SQDIST) {
+            s = -d1;
+        } else {
+            const float* su = e.U2 + u * e.k;
+            const float* qi = e.I2 + it * e.k;
+            const float d2 = np_pairwise_sum([&](int c) { const float d = su[c] - qi[c]; return d * d; }, e.k);
+            const float t1 = (-e.w1) * d1;
+            const float t2 = e.w2 * d2;
+            s = t1 - t2;
+        }
+    }
+    if (e.bias) s = s + e.bias[it];
+    return s;
+}
+
+// max |x[i]| over i < n into out[0] (one block; n is a table's row count)
+__global__ __launch_bounds__(1024) void max_abs_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float m = 0.0f;
+    if (x)
+        for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// target prologue of the exact path: reference-order score of every held-out item, its band, masked flag, counters
+// un[u] = -|u'|^2 (neg_sqnorm_kernel; weighted for the two-distance score), in_max[0] = max_i |i'|^2,
+// bmax[0] = max |bias|.  d_eff = length of the MFMA dot product (2k for the two-distance score).
+// delta bounds |MFMA score - reference-order score| for every item: both are fp32 evaluations of the same real
+// number whose summands are bounded by (|u'|^2 + |i'|^2) in absolute value; (2 D + 2 d + 16) roundings at most.
+__global__ __launch_bounds__(256) void exact_prologue_kernel(ExactArgs e, int d_eff, const float* __restrict__ un,
+                                                             const float* __restrict__ in_max,
+                                                             const float* __restrict__ bmax,
+                                                             const int32_t* __restrict__ train_ptr,
+                                                             const int32_t* __restrict__ train_idx,
+                                                             const int32_t* __restrict__ tgt_ptr,
+                                                             const int32_t* __restrict__ tgt_idx,
+                                                             float* __restrict__ tgt_ref, float* __restrict__ tgt_lo,
+                                                             float* __restrict__ tgt_hi,
+                                                             int32_t* __restrict__ tgt_masked,
+                                                             int32_t* __restrict__ tgt_rank,
+                                                             int32_t* __restrict__ band_count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) band_count[0] = 0;
+    const float c1 = 4.0f * (float)(d_eff + 8) * 5.9604645e-08f * 1.01f;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < e.Nu; u += (int64_t)gridDim.x * 256) {
+        const int tb = tgt_ptr[u], te = tgt_ptr[u + 1];
+        const float delta = c1 * ((-un[u]) + in_max[0]) + 8.0f * 5.9604645e-08f * bmax[0];
+        for (int x = tb; x < te; ++x) {
+            const int64_t it = tgt_idx[x];
+            bool masked = it < 0 || it >= e.Ni;
+            if (!masked && train_ptr) {
+                int lo = train_ptr[u], hi = train_ptr[u + 1];
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (train_idx[mid] < it) lo = mid + 1; else hi = mid;
+                }
+                masked = lo < train_ptr[u + 1] && train_idx[lo] == it;
+            }
+            float s = 0.0f;
+            if (!masked) {
+                s = ref_order_score(e, u, it);
+                if (s != s) masked = true;
+            }
+            tgt_ref[x] = s;
+            tgt_lo[x] = s - delta;
+            tgt_hi[x] = s + delta;
+            tgt_masked[x] = masked ? 1 : 0;
+            tgt_rank[x] = 0;
+        }
+    }
+}
+
+// exact re-score of the band entries: one thread per (user row, target slot, item)
+__global__ __launch_bounds__(256) void exact_refine_kernel(ExactArgs e, const int32_t* __restrict__ band_list,
+                                                           const int32_t* __restrict__ band_count, int band_cap,
+                                                           const int32_t* __restrict__ tgt_idx,
+                                                           const float* __restrict__ tgt_ref,
+                                                           int32_t* __restrict__ tgt_rank) {
+    const int n = band_count[0];
+    if (n > band_cap) return;  // overflowed: exact_fallback_kernel recounts everything
+    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < n; y += (int64_t)gridDim.x * 256) {
+        const int64_t u = band_list[3 * y];
+        const int x = band_list[3 * y + 1];
+        const int item = band_list[3 * y + 2];
+        const float s = ref_order_score(e, u, item);
+        if (s == s && beats(s, item, tgt_ref[x], tgt_idx[x])) atomicAdd(tgt_rank + x, 1);
+    }
+}
+
+// band list overflowed (degenerate inputs: a large part of the catalog within rounding distance of a held-out item):
+// every rank is recounted from reference-order scores of the whole catalog, one block per user
+__global__ __launch_bounds__(256) void exact_fallback_kernel(ExactArgs e, const int32_t* __restrict__ band_count,
+                                                             int band_cap, const int32_t* __restrict__ train_ptr,
+                                                             const int32_t* __restrict__ train_idx,
+                                                             const int32_t* __restrict__ tgt_ptr,
+                                                             const int32_t* __restrict__ tgt_idx,
+                                                             const float* __restrict__ tgt_ref,
+                                                             const int32_t* __restrict__ tgt_masked,
+                                                             int32_t* __restrict__ tgt_rank) {
+    if (band_count[0] <= band_cap) return;
+    __shared__ int rc[256];
+    const int tid = threadIdx.x;
+    for (int64_t u = blockIdx.x; u < e.Nu; u += gridDim.x) {
+        const int tb = train_ptr ? train_ptr[u] : 0, te = train_ptr ? train_ptr[u + 1] : 0;
+        for (int x = tgt_ptr[u]; x < tgt_ptr[u + 1]; ++x) {
+            if (tgt_masked[x]) continue;  // block-uniform
+            const float st = tgt_ref[x];
+            const int ct = tgt_idx[x];
+            int cnt = 0;
+            for (int64_t c = tid; c < e.Ni; c += 256) {
+                int lo = tb, hi = te;
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (train_idx[mid] < c) lo = mid + 1; else hi = mid;
+                }
+                if (lo < te && train_idx[lo] == c) continue;
+                const float s = ref_order_score(e, u, c);
+                if (s == s && beats(s, (int)c, st, ct)) ++cnt;
+            }
+            rc[tid] = cnt;
+            __syncthreads();
+            for (int s2 = 128; s2 > 0; s2 >>= 1) {
+                if (tid < s2) rc[tid] += rc[tid + s2];
+                __syncthreads();
+            }
+            if (tid == 0) tgt_rank[x] = rc[0];
+            __syncthreads();
+        }
+    }
+}
+
+struct ExactLayout {
+    int64_t topk, tgt_ref, tgt_hi, un, in, scal, band_count, band_list, total;
+    int64_t band_cap;
+    TopkLayout T;
+};
+static void exact_layout(int64_t Nu, int64_t Ni, int k, int64_t ntgt, int kind, ExactLayout* E) {
+    topk_layout(Nu, Ni, k, 1, ntgt, kind, &E->T);
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        int64_t o = off;
+        off += align_up(bytes > 0 ? bytes : 1, 256);
+        return o;
+    };
+    E->topk = take(E->T.total);
+    E->tgt_ref = take(ntgt * 4);
+    E->tgt_hi = take(ntgt * 4);
+    E->un = take(Nu * 4);
+    E->in = take(Ni * 4);
+    E->scal = take(256);
+    E->band_count = take(256);
+    E->band_cap = 64 * ntgt + 65536;
+    if (E->band_cap > (1ll << 30)) E->band_cap = 1ll << 30;
+    E->band_list = take(E->band_cap * 12);
+    E->total = off;
 }
 
 static int check_score_args(const float* U, const float* U2, int64_t Nu, const float* I, const float* I2, int64_t Ni,
@@ -1268,7 +1568,7 @@ extern "C" int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu
     char* base = (char*)ws;
     ScoreArgs a;
     memset(&a, 0, sizeof(a));
-    rc = prepare_operands(U, U2, Nu, I, I2, item_bias, Ni, k, score_kind, alpha, base, L, st, &a);
+    rc = prepare_operands(U, U2, Nu, I, I2, item_bias, Ni, k, score_kind, alpha, 1.0f - alpha, base, L, st, &a);
     if (rc != DR_OK) return rc;
     a.Nu = Nu;
     a.Ni = Ni;
@@ -1341,7 +1641,7 @@ extern "C" int32_t dr_score_matrix_f32(const float* U, const float* U2, int64_t 
     hipStream_t st = (hipStream_t)stream;
     ScoreArgs a;
     memset(&a, 0, sizeof(a));
-    rc = prepare_operands(U, U2, Nu, I, I2, item_bias, Ni, k, score_kind, alpha, (char*)ws, L, st, &a);
+    rc = prepare_operands(U, U2, Nu, I, I2, item_bias, Ni, k, score_kind, alpha, 1.0f - alpha, (char*)ws, L, st, &a);
     if (rc != DR_OK) return rc;
     a.Nu = Nu;
     a.Ni = Ni;
@@ -1396,5 +1696,95 @@ extern "C" int32_t dr_topk_rank_f32(const float* scores, int64_t Nu, int64_t Ni,
                            n_targets, tgt_rank);
         DR_CHECK_LAUNCH("target_finalize_kernel");
     }
+    return DR_OK;
+}
+
+extern "C" int64_t dr_score_rank_exact_bytes(int64_t Nu, int64_t Ni, int32_t k, int64_t n_targets, int32_t score_kind) {
+    if (Nu < 0 || Ni < 0 || k < 1 || n_targets < 0) return DR_ERR_ARG;
+    ExactLayout E;
+    exact_layout(Nu, Ni, k, n_targets, score_kind, &E);
+    return E.total;
+}
+
+extern "C" int32_t dr_score_rank_exact_f32(const float* U, const float* U2, int64_t Nu, const float* I, const float* I2,
+                                           const float* item_bias, int64_t Ni, int32_t k, int32_t score_kind, float w1,
+                                           float w2, const int32_t* train_ptr, const int32_t* train_idx,
+                                           const int32_t* tgt_ptr, const int32_t* tgt_idx, int64_t n_targets,
+                                           int32_t* tgt_rank, void* ws, int64_t ws_bytes, void* stream) {
+    int rc = check_score_args(U, U2, Nu, I, I2, Ni, k, score_kind, "dr_score_rank_exact_f32");
+    if (rc != DR_OK) return rc;
+    DR_REQUIRE(k <= 8192, "dr_score_rank_exact_f32: k must be <= 8192");
+    DR_REQUIRE(n_targets >= 0 && (n_targets == 0 || (tgt_ptr && tgt_idx && tgt_rank)),
+               "dr_score_rank_exact_f32: target CSR / rank output is NULL");
+    DR_REQUIRE((train_ptr == nullptr) == (train_idx == nullptr) || train_ptr, "dr_score_rank_exact_f32: train CSR incomplete");
+    DR_REQUIRE(ws && ((uintptr_t)ws % 256 == 0), "dr_score_rank_exact_f32: workspace NULL / misaligned");
+    if (Nu == 0 || n_targets == 0) return DR_OK;
+    ExactLayout E;
+    exact_layout(Nu, Ni, k, n_targets, score_kind, &E);
+    if (ws_bytes < E.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_score_rank_exact_f32: workspace %lld < required %lld", (long long)ws_bytes,
+                (long long)E.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)ws + E.topk;
+    const TopkLayout& L = E.T;
+    ScoreArgs a;
+    memset(&a, 0, sizeof(a));
+    rc = prepare_operands(U, U2, Nu, I, I2, item_bias, Ni, k, score_kind, w1, w2, base, L, st, &a);
+    if (rc != DR_OK) return rc;
+    a.Nu = Nu;
+    a.Ni = Ni;
+    a.train_ptr = train_ptr;
+    a.train_idx = train_idx;
+    a.K = 1;
+    a.ntiles = L.ntiles;
+    a.tiles_per_split = L.tiles_per_split;
+    a.part_v = (float*)(base + L.part_v);
+    a.part_i = (int32_t*)(base + L.part_i);
+    a.tgt_ptr = tgt_ptr;
+    a.tgt_idx = tgt_idx;
+    a.tgt_score = (float*)(base + L.tgt_score);  // lower end of the band
+    a.tgt_masked = (int32_t*)(base + L.tgt_masked);
+    a.tgt_rank = tgt_rank;
+    char* xb = (char*)ws;
+    float* tgt_ref = (float*)(xb + E.tgt_ref);
+    float* tgt_hi = (float*)(xb + E.tgt_hi);
+    float* un = (float*)(xb + E.un);
+    float* in = (float*)(xb + E.in);
+    float* scal = (float*)(xb + E.scal);
+    a.tgt_hi = tgt_hi;
+    a.band_list = (int32_t*)(xb + E.band_list);
+    a.band_count = (int32_t*)(xb + E.band_count);
+    a.band_cap = (int)E.band_cap;
+    // (weighted) squared norms of both sides, as the MFMA operands see them; max over the catalog; max |bias|
+    const bool two = score_kind == DR_SCORE_TWO_DIST;
+    const float n1 = two ? w1 : 1.0f, n2 = two ? w2 : 0.0f;
+    DR_LAUNCH(neg_sqnorm_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, U, two ? U2 : (const float*)nullptr, Nu, k, n1, n2, un);
+    if (Ni > 0)
+        DR_LAUNCH(neg_sqnorm_kernel, dim3(grid_for(Ni, 256)), dim3(256), 0, st, I, two ? I2 : (const float*)nullptr, Ni, k, n1, n2, in);
+    DR_LAUNCH(max_abs_kernel, dim3(1), dim3(1024), 0, st, (const float*)in, Ni, scal);
+    DR_LAUNCH(max_abs_kernel, dim3(1), dim3(1024), 0, st, item_bias, Ni, scal + 1);
+    DR_CHECK_LAUNCH("dr_score_rank_exact_f32: norms");
+    ExactArgs e;
+    e.U = U; e.U2 = U2; e.I = I; e.I2 = I2; e.bias = item_bias;
+    e.Nu = Nu; e.Ni = Ni; e.k = k; e.kind = score_kind; e.w1 = w1; e.w2 = w2;
+    DR_LAUNCH(exact_prologue_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, e, a.k, (const float*)un,
+              (const float*)scal, (const float*)(scal + 1), train_ptr, train_idx, tgt_ptr, tgt_idx, tgt_ref,
+              (float*)(base + L.tgt_score), tgt_hi, (int32_t*)(base + L.tgt_masked), tgt_rank, a.band_count);
+    DR_CHECK_LAUNCH("exact_prologue_kernel");
+    const int64_t panels = (Nu + TU - 1) / TU;
+    DR_REQUIRE(panels < (1ll << 31), "dr_score_rank_exact_f32: too many user panels");
+    rc = launch_score_band(a, dim3((unsigned)panels, (unsigned)L.S), st);
+    if (rc != DR_OK) return rc;
+    DR_LAUNCH(exact_refine_kernel, dim3(grid_for(E.band_cap < (1 << 22) ? E.band_cap : (1 << 22), 256)), dim3(256), 0, st, e,
+              (const int32_t*)a.band_list, (const int32_t*)a.band_count, a.band_cap, tgt_idx, (const float*)tgt_ref,
+              tgt_rank);
+    DR_CHECK_LAUNCH("exact_refine_kernel");
+    DR_LAUNCH(exact_fallback_kernel, dim3((unsigned)(Nu < 2048 ? Nu : 2048)), dim3(256), 0, st, e,
+              (const int32_t*)a.band_count, a.band_cap, train_ptr, train_idx, tgt_ptr, tgt_idx, (const float*)tgt_ref,
+              (const int32_t*)(base + L.tgt_masked), tgt_rank);
+    DR_CHECK_LAUNCH("exact_fallback_kernel");
+    DR_LAUNCH(target_finalize_kernel, dim3(grid_for(n_targets, 256)), dim3(256), 0, st,
+              (const int32_t*)(base + L.tgt_masked), n_targets, tgt_rank);
+    DR_CHECK_LAUNCH("target_finalize_kernel");
     return DR_OK;
 }

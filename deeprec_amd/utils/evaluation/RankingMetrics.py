@@ -9,50 +9,22 @@ predict + Python sort by one full-catalog scoring + masked top-K + rank-of-targe
   * any other model -> model.predict over each user's candidates, selection by dr_topk_rank_f32.
 It prints what the reference prints and additionally RETURNS the dict of the nine means.
 """
-import math
-
 import numpy as np
 import torch
 
-from ._ranks import masked_items, pack_csr, ranking_user_metrics, split_ranks
+from ._ranks import (cutoff_metrics, full_list_metrics, hit_positions, masked_items, pack_csr, ranking_user_metrics,
+                     split_ranks)
 
 
-# efficient version
 def precision_recall_ndcg_at_k(k, rankedlist, test_matrix):
-    """RankingMetrics.py:21-37."""
-    idcg_k = 0
-    dcg_k = 0
-    n_k = k if len(test_matrix) > k else len(test_matrix)
-    for i in range(n_k):
-        idcg_k += 1 / math.log(i + 2, 2)
-    s2 = set(test_matrix)
-    hits = [(idx, val) for idx, val in enumerate(rankedlist) if val in s2]
-    count = len(hits)
-    for c in range(count):
-        dcg_k += 1 / math.log(hits[c][0] + 2, 2)
-    return float(count / k), float(count / len(test_matrix)), float(dcg_k / idcg_k)
+    """RankingMetrics.py:21-37 -- `rankedlist` is the ranking already cut at k."""
+    hits, recall, ndcg = cutoff_metrics(hit_positions(rankedlist, test_matrix), k, len(test_matrix))
+    return float(hits / k), recall, ndcg
 
 
 def map_mrr_ndcg(rankedlist, test_matrix):
-    """RankingMetrics.py:40-65."""
-    ap = 0
-    map = 0
-    dcg = 0
-    idcg = 0
-    mrr = 0
-    for i in range(len(test_matrix)):
-        idcg += 1 / math.log(i + 2, 2)
-    s2 = set(test_matrix)
-    hits = [(idx, val) for idx, val in enumerate(rankedlist) if val in s2]
-    count = len(hits)
-    for c in range(count):
-        ap += (c + 1) / (hits[c][0] + 1)
-        dcg += 1 / math.log(hits[c][0] + 2, 2)
-    if count != 0:
-        mrr = 1 / (hits[0][0] + 1)
-    if count != 0:
-        map = ap / count
-    return map, mrr, float(dcg / idcg)
+    """RankingMetrics.py:40-65 over the full ranking."""
+    return full_list_metrics(hit_positions(rankedlist, test_matrix), len(test_matrix))
 
 
 def rank_targets(model, users, K=10):
@@ -75,6 +47,13 @@ def rank_targets(model, users, K=10):
         idx, _, rank = Kn.score_topk(ops["U"], ops["I"], K, score_kind=ops.get("kind", Kn.SCORE_DOT),
                                      U2=ops.get("U2"), I2=ops.get("I2"), alpha=ops.get("alpha", 0.0),
                                      item_bias=ops.get("item_bias"), train=(tp, ti), targets=(gp, gi))
+        if ops.get("order") == "numpy" and gi.numel():
+            # the model's predict() is numpy float32 arithmetic (pairwise-summed products / squared differences):
+            # ranks are made exact with respect to THAT operation order (dr_score_rank_exact_f32)
+            a = float(ops.get("alpha", 0.0))
+            rank = Kn.score_rank_exact(ops["U"], ops["I"], (gp, gi), score_kind=ops.get("kind", Kn.SCORE_DOT),
+                                       U2=ops.get("U2"), I2=ops.get("I2"), w1=np.float32(a), w2=np.float32(1 - a),
+                                       item_bias=ops.get("item_bias"), train=(tp, ti))
     elif hasattr(model, "eval_scores"):
         idx, _, rank = Kn.topk_rank(model.eval_scores(users), K, train=(tp, ti), targets=(gp, gi))
     else:

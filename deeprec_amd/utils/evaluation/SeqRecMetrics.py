@@ -9,49 +9,24 @@ Deviation kept explicit: the reference indexes `results[u, j]` with the user ID 
 row per entry of test_users (SeqRecMetrics.py:107,141) -- only consistent when test_users == range(n).
 Here row r of the user parameters belongs to test_users[r].
 """
-import math
-
 import numpy as np
 import torch
 
-from ._ranks import masked_items, pack_csr, seq_user_metrics, split_ranks
+from ._ranks import (cutoff_metrics, full_list_metrics, hit_positions, masked_items, pack_csr, seq_user_metrics,
+                     split_ranks)
 
 
 def precision_recall_ndcg_at_k(k, rankedlist, test_matrix):
-    """SeqRecMetrics.py:23-43 (first value is the hit COUNT)."""
-    idcg_k = 0
-    dcg_k = 0
-    n_k = k if len(test_matrix) > k else len(test_matrix)
-    for i in range(n_k):
-        idcg_k += 1 / math.log(i + 2, 2)
-    s2 = set(test_matrix)
-    hits = [(idx, val) for idx, val in enumerate(rankedlist) if val in s2]
-    count = len(hits)
-    for c in range(count):
-        dcg_k += 1 / math.log(hits[c][0] + 2, 2)
-    return count, float(count / len(test_matrix)), float(dcg_k / idcg_k)
+    """SeqRecMetrics.py:23-43 (the first value is the hit COUNT, not a precision)."""
+    return cutoff_metrics(hit_positions(rankedlist, test_matrix), k, len(test_matrix))
 
 
 def map_mrr_ndcg(rankedlist, test_matrix):
-    """SeqRecMetrics.py:47-81 (first value is AUC)."""
-    ap = 0
-    dcg = 0
-    idcg = 0
-    mrr = 0
-    for i in range(len(test_matrix)):
-        idcg += 1 / math.log(i + 2, 2)
-    s2 = set(test_matrix)
-    hits = [(idx, val) for idx, val in enumerate(rankedlist) if val in s2]
-    count = len(hits)
-    for c in range(count):
-        ap += (c + 1) / (hits[c][0] + 1)
-        dcg += 1 / math.log(hits[c][0] + 2, 2)
-    if count != 0:
-        mrr = 1 / (hits[0][0] + 1)
-    max = len(rankedlist) - 1
-    count_test = max - hits[0][0] if count != 0 else 0
-    auc = 1.0 * count_test / max
-    return auc, mrr, float(dcg / idcg)
+    """SeqRecMetrics.py:47-81 (the first value is AUC = (N - 1 - first hit) / (N - 1) over the N candidates)."""
+    hits = hit_positions(rankedlist, test_matrix)
+    _, mrr, ndcg = full_list_metrics(hits, len(test_matrix))
+    _, _, auc = seq_user_metrics(hits, len(test_matrix), len(rankedlist))
+    return auc, mrr, ndcg
 
 
 def _t(a, dev):
@@ -60,7 +35,7 @@ def _t(a, dev):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)
 
 
-def _rank(self, users, U, I, kind, U2=None, I2=None, alpha=0.0, bias=None, scores=None):
+def _rank(self, users, U, I, kind, U2=None, I2=None, alpha=0.0, bias=None, scores=None, numpy_order=False):
     from ... import kernels as Kn
     dev = torch.device(getattr(self, "device", "cuda:0"))
     num_item = int(self.num_item)
@@ -72,6 +47,13 @@ def _rank(self, users, U, I, kind, U2=None, I2=None, alpha=0.0, bias=None, score
         # HR@50 / MRR / AUC depend on the ranks of the held-out items only (SeqRecMetrics.py:33,59,75-80): no top-50
         # list is kept (K = 1), the rank counters are the same
         _, _, rank = Kn.topk_rank(scores, 1, train=(tp, ti), targets=(gp, gi))
+    elif numpy_order:
+        # ranks exact in the reference's own float32 operation order (SeqRecMetrics.py:122-123 is numpy arithmetic):
+        # MFMA pass + exact re-score of the near-ties (dr_score_rank_exact_f32)
+        rank = Kn.score_rank_exact(_t(U, dev), _t(I, dev), (gp, gi), score_kind=kind,
+                                   U2=None if U2 is None else _t(U2, dev), I2=None if I2 is None else _t(I2, dev),
+                                   w1=np.float32(alpha), w2=np.float32(1 - alpha),
+                                   item_bias=None if bias is None else _t(bias, dev).reshape(-1), train=(tp, ti))
     else:
         _, _, rank = Kn.score_topk(_t(U, dev), _t(I, dev), 1, score_kind=kind,
                                    U2=None if U2 is None else _t(U2, dev), I2=None if I2 is None else _t(I2, dev),
@@ -107,7 +89,7 @@ def evaluate1(self):
     print(np.shape(user_factors))
     print(np.shape(item_factors_1))
     ranks, n_cand = _rank(self, users, user_factors, item_factors_1, Kn.SCORE_TWO_DIST, seq_factors, item_factors_2,
-                          float(self.alpha))
+                          float(self.alpha), numpy_order=True)
     return _report(self, users, ranks, n_cand, True)
 
 

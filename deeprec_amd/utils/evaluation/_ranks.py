@@ -36,6 +36,36 @@ def _idcg(n):
     return s
 
 
+def hit_positions(rankedlist, test_items):
+    """Sorted 0-based positions in `rankedlist` of the entries that are held-out items."""
+    wanted = set(test_items)
+    return [pos for pos, item in enumerate(rankedlist) if item in wanted]
+
+
+def _dcg(positions):
+    s = 0
+    for r in positions:
+        s += 1 / math.log(r + 2, 2)
+    return s
+
+
+def cutoff_metrics(hit_ranks, k, n_test):
+    """(hits within the list, recall, ndcg) for a list that was cut at k: every entry of hit_ranks is < k.
+    precision = hits / k (RankingMetrics.py:37); the sequence evaluator reports the hit count itself
+    (SeqRecMetrics.py:43)."""
+    return len(hit_ranks), float(len(hit_ranks) / n_test), float(_dcg(hit_ranks) / _idcg(k if n_test > k else n_test))
+
+
+def full_list_metrics(hit_ranks, n_test):
+    """(average precision, reciprocal rank, ndcg) over the whole ranking (RankingMetrics.py:40-65)."""
+    ap = 0
+    for c, r in enumerate(hit_ranks):
+        ap += (c + 1) / (r + 1)
+    mp = ap / len(hit_ranks) if hit_ranks else 0
+    mrr = 1 / (hit_ranks[0] + 1) if hit_ranks else 0
+    return mp, mrr, float(_dcg(hit_ranks) / _idcg(n_test))
+
+
 def ranking_user_metrics(hit_ranks, n_test):
     """(p5, r5, ndcg5, p10, r10, ndcg10, map, mrr, ndcg) from sorted 0-based hit ranks
     (RankingMetrics.py:21-65)."""

@@ -258,6 +258,28 @@ int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu, const flo
                           int64_t n_targets, int32_t K, int32_t* topk_idx, float* topk_score,
                           int32_t* tgt_rank, void* ws, int64_t ws_bytes, void* stream);
 
+/* Ranks of the held-out items in the REFERENCE's float32 operation order.  The reference's evaluators
+ * score in numpy -- SeqRecMetrics.py:122-123: -alpha * np.sum((p[:,None] - X)**2, axis=2) - (1 - alpha) * np.sum(...),
+ * i.e. separately rounded differences and squares added by numpy's pairwise summation -- while dr_score_topk_f32
+ * computes the expanded form as fmaf chains on the matrix cores; the two agree to a few ulps, so near-tied
+ * neighbours can swap.  This entry point keeps the MFMA pass but lets it decide only what is certain: a candidate whose
+ * MFMA score differs from the held-out item's reference-order score by more than a proven bound on the rounding
+ * difference is counted (or not) at once; the few inside the band are re-scored in the reference's order and
+ * compared exactly (ties: lower item id first, RankingMetrics.py:98).  tgt_rank therefore equals the rank the
+ * reference's stable sort gives, bit for bit of the float32 scores.  Score kinds, in numpy float32 arithmetic:
+ *   DR_SCORE_DOT         (p * q).sum() [+ item_bias]     DR_SCORE_NEG_SQDIST   -((p - q)**2).sum()
+ *   DR_SCORE_TWO_DIST    (-w1) * ((p - X)**2).sum() - w2 * ((s - Q)**2).sum()   (w1 = float32(alpha), w2 = float32(1 - alpha))
+ * np.dot (BLAS, SeqRecMetrics.py:213) has no fixed operation order and is not offered.  k <= 8192.
+ * ws: dr_score_rank_exact_bytes(...) (holds the band list: 12 bytes x (64 n_targets + 65536) entries; if it ever
+ * overflows -- a large part of the catalog within rounding distance of a held-out item -- every rank is recounted
+ * from reference-order scores of the whole catalog, slower but still exact). */
+int64_t dr_score_rank_exact_bytes(int64_t Nu, int64_t Ni, int32_t k, int64_t n_targets, int32_t score_kind);
+int32_t dr_score_rank_exact_f32(const float* U, const float* U2, int64_t Nu, const float* I, const float* I2,
+                                const float* item_bias, int64_t Ni, int32_t k, int32_t score_kind, float w1,
+                                float w2, const int32_t* train_ptr, const int32_t* train_idx,
+                                const int32_t* tgt_ptr, const int32_t* tgt_idx, int64_t n_targets,
+                                int32_t* tgt_rank, void* ws, int64_t ws_bytes, void* stream);
+
 /* Same selection on a caller-provided score matrix scores[Nu, Ni] (NeuMF / any model
  * whose score is not a bilinear form; RankingMetrics.py:91-101).  ws: 2 * round_up(4 *
  * n_targets, 256) bytes when n_targets > 0. */

@@ -469,6 +469,53 @@ def topk_and_ranks(score_row, train_items, targets, K):
     return top, score_row[top], ranks
 
 
+def np_pairwise_sum(a):
+    """numpy's float32 pairwise summation restated element by element (numpy/_core/src/umath/loops_utils.h.src,
+    *_pairwise_sum) -- the order np.sum(..., axis=-1) adds the summands of SeqRecMetrics.py:122-123 in.  The HIP
+    kernels of dr_score_rank_exact_f32 follow this restatement; tests/test_golden_cpu.py pins it against numpy."""
+    a = np.asarray(a, f32)
+    n = len(a)
+    if n < 8:
+        res = f32(0.0)
+        for x in a:
+            res = f32(res + x)
+        return res
+    if n <= 128:
+        r = [f32(a[q]) for q in range(8)]
+        c = 8
+        while c < n - (n % 8):
+            for q in range(8):
+                r[q] = f32(r[q] + a[c + q])
+            c += 8
+        res = f32(f32(f32(r[0] + r[1]) + f32(r[2] + r[3])) + f32(f32(r[4] + r[5]) + f32(r[6] + r[7])))
+        while c < n:
+            res = f32(res + a[c])
+            c += 1
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return f32(np_pairwise_sum(a[:n2]) + np_pairwise_sum(a[n2:]))
+
+
+def numpy_order_scores(kind, U, I, U2=None, I2=None, w1=0.0, w2=0.0, bias=None):
+    """All-pairs scores in the reference evaluators' own numpy float32 arithmetic:
+    kind 0: (p * q).sum() [+ bias]; 1: -((p - q) ** 2).sum();
+    2: SeqRecMetrics.py:122-123 literally, -alpha * np.sum((p[:, None] - X) ** 2, axis=2) - (1 - alpha) * np.sum(...)
+    with alpha = w1, 1 - alpha = w2 given as float32."""
+    U, I = np.asarray(U, f32), np.asarray(I, f32)
+    if kind == 0:
+        s = np.sum(U[:, None] * I, axis=2)
+    elif kind == 1:
+        s = -np.sum((U[:, None] - I) ** 2, axis=2)
+    else:
+        U2, I2 = np.asarray(U2, f32), np.asarray(I2, f32)
+        s = -f32(w1) * np.sum((U[:, None] - I) ** 2, axis=2) - f32(w2) * np.sum((U2[:, None] - I2) ** 2, axis=2)
+    if bias is not None:
+        s = s + np.asarray(bias, f32)
+    assert s.dtype == f32
+    return s
+
+
 # --------------------------------------------------------------------------
 # metrics (pinned against goldens generated from the reference's own numpy
 # evaluator: tests/golden/metrics_*.json)

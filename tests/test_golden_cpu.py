@@ -48,6 +48,30 @@ def test_metric_functions_oracle_and_product():
         assert ro.RMSE(r["err"], r["n"]) == r["rmse"] and ro.MAE(r["err"], r["n"]) == r["mae"]
 
 
+def test_numpy_pairwise_restatement_equals_numpy():
+    """oracle.ref_ops.np_pairwise_sum (the order dr_score_rank_exact_f32's re-score follows) against numpy itself, the
+    arithmetic of SeqRecMetrics.py:122-123, on every length class of the algorithm."""
+    rng = np.random.default_rng(3)
+    for d in (1, 5, 7, 8, 9, 16, 17, 40, 127, 128, 129, 150, 200, 256, 300, 513, 1100):
+        a = (rng.standard_normal((3, d)) * 10 ** rng.uniform(-3, 3)).astype(np.float32)
+        b = rng.standard_normal((4, d)).astype(np.float32)
+        R = np.sum((a[:, None] - b) ** 2, axis=2)
+        Dt = np.sum(a[:, None] * b, axis=2)
+        for u in range(3):
+            for i in range(4):
+                t = a[u] - b[i]
+                assert ro.np_pairwise_sum(t * t) == R[u, i], d
+                assert ro.np_pairwise_sum(a[u] * b[i]) == Dt[u, i], d
+                assert ro.np_pairwise_sum(a[u] * b[i]) == (a[u] * b[i]).sum(), d
+    # numpy_order_scores is the reference's expression itself
+    P, S = rng.standard_normal((5, 40)).astype(np.float32), rng.standard_normal((5, 40)).astype(np.float32)
+    X, Q = rng.standard_normal((9, 40)).astype(np.float32), rng.standard_normal((9, 40)).astype(np.float32)
+    alpha = 0.2
+    ref = -alpha * np.sum((P[:, None] - X) ** 2, axis=2) - (1 - alpha) * np.sum((S[:, None] - Q) ** 2, axis=2)
+    got = ro.numpy_order_scores(2, P, X, S, Q, np.float32(alpha), np.float32(1 - alpha))
+    assert ref.dtype == np.float32 and np.array_equal(ref, got)
+
+
 def _neg(train, ni):
     return {u: [i for i in range(ni) if i not in set(t)] for u, t in enumerate(train)}
 

@@ -518,6 +518,75 @@ def test_score_topk_distances(dev, kind):
     np.testing.assert_allclose(scores, direct, rtol=1e-5, atol=1e-6)
 
 
+def _near_tie_items(rng, I):
+    """every odd row = its even neighbour with one coordinate moved by one ulp (scores differ in the last bits only)"""
+    for r in range(0, I.shape[0] - 1, 2):
+        I[r + 1] = I[r]
+        c = int(rng.integers(0, I.shape[1]))
+        I[r + 1, c] = np.nextafter(I[r, c], np.float32(np.inf if rng.integers(0, 2) else -np.inf), dtype=np.float32)
+
+
+def _exact_ranks(scores, train, tgt):
+    out = []
+    for u in range(scores.shape[0]):
+        out.append(ro.topk_and_ranks(scores[u], train[u], tgt[u], 1)[2])
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
+@pytest.mark.parametrize("kind,k", [(0, 5), (0, 40), (0, 150), (1, 100), (2, 5), (2, 40), (2, 150), (2, 200), (0, 300)])
+def test_score_rank_exact_in_numpy_order(dev, kind, k):
+    """dr_score_rank_exact_f32: ranks of the held-out items equal those of a stable sort of the reference's own
+    numpy float32 scores (SeqRecMetrics.py:122-123 literally; (p*q).sum(); -((p-q)**2).sum()), bit for bit of the
+    scores, on a catalog made of forced near-ties.  The plain MFMA ranking (fmaf-chain scores) differs on the same
+    input -- that difference is what the exact re-score removes."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(100 * kind + k)
+    Nu, Ni = 150, 1101
+    U, I, train, tgt = _eval_case(rng, Nu, Ni, k, 30, 3, std=0.3)
+    U2 = (rng.standard_normal((Nu, k)) * 0.3).astype(np.float32)
+    I2 = (rng.standard_normal((Ni, k)) * 0.3).astype(np.float32)
+    _near_tie_items(rng, I)
+    _near_tie_items(rng, I2)
+    bias = None
+    if kind == 0 and k == 40:
+        bias = rng.standard_normal(Ni).astype(np.float32)
+        bias[1::2] = bias[0:-1:2]
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    w1, w2 = np.float32(0.2), np.float32(1 - 0.2)
+    kw = dict(U2=T(U2, dev), I2=T(I2, dev)) if kind == 2 else {}
+    rank = N(K.score_rank_exact(T(U, dev), T(I, dev), (T(gp, dev), T(gi, dev)), score_kind=kind, w1=w1, w2=w2,
+                                item_bias=None if bias is None else T(bias, dev), train=(T(tp, dev), T(ti, dev)), **kw))
+    ref = ro.numpy_order_scores(kind, U, I, U2, I2, w1, w2, bias)
+    want = _exact_ranks(ref, train, tgt)
+    assert np.array_equal(rank, want), "%d of %d ranks differ" % ((rank != want).sum(), len(want))
+    # the canonical fmaf-chain ranking is a different (equally valid) order on near-ties
+    _, _, r_mfma = K.score_topk(T(U, dev), T(I, dev), 1, score_kind=kind, alpha=0.2,
+                                item_bias=None if bias is None else T(bias, dev), train=(T(tp, dev), T(ti, dev)),
+                                targets=(T(gp, dev), T(gi, dev)), **kw)
+    if k >= 40:
+        assert (N(r_mfma) != want).any()
+
+
+def test_score_rank_exact_band_overflow_falls_back(dev):
+    """A catalog of identical rows puts every candidate inside every held-out item's band: the band list overflows
+    and the whole-catalog recount takes over -- still exact (ties: lower item id first)."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(5)
+    Nu, Ni, k = 128, 3000, 24
+    U = rng.standard_normal((Nu, k)).astype(np.float32)
+    I = np.repeat(rng.standard_normal((1, k)).astype(np.float32), Ni, 0)
+    I[::7] = np.nextafter(I[::7], np.float32(np.inf), dtype=np.float32)
+    train = [np.sort(rng.permutation(Ni)[:5]) for _ in range(Nu)]
+    tgt = [np.array([int(rng.integers(0, Ni))]) for _ in range(Nu)]
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    rank = N(K.score_rank_exact(T(U, dev), T(I, dev), (T(gp, dev), T(gi, dev)), score_kind=1,
+                                train=(T(tp, dev), T(ti, dev))))
+    want = _exact_ranks(ro.numpy_order_scores(1, U, I), train, tgt)
+    assert np.array_equal(rank, want)
+
+
 def test_score_topk_caser_bias(dev):
     """SeqRecMetrics.py:213: user_factors @ item_factors.T + bias_item."""
     from deeprec_amd import kernels as K

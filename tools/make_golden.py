@@ -99,11 +99,25 @@ def stub_case(seed, nu, ni, k, quantise):
     return P.astype(np.float32), Q.astype(np.float32), train, test
 
 
+def near_ties(*tables):
+    """Forced NEAR-ties: every odd row becomes its even neighbour with one coordinate moved by one ulp, so that for every
+    user the two items' scores differ in the last bits only -- which of the two ranks first then depends on the
+    exact float32 operation order of the scoring."""
+    rng = np.random.default_rng(99)
+    for T in tables:
+        for r in range(0, T.shape[0] - 1, 2):
+            T[r + 1] = T[r]
+            c = int(rng.integers(0, T.shape[1]))
+            T[r + 1, c] = np.nextafter(T[r, c], np.float32(np.inf if rng.integers(0, 2) else -np.inf), dtype=np.float32)
+
+
 def g2():
     out = []
-    for seed, quant in [(1, False), (2, True), (3, True)]:
-        nu, ni, k = 23, 97, 6
-        P, Q, train, test = stub_case(seed, nu, ni, k, quant)
+    for seed, quant, k in [(1, False, 6), (2, True, 6), (3, True, 6), (7, "near", 24)]:
+        nu, ni = 23, 97
+        P, Q, train, test = stub_case(seed, nu, ni, k, quant is True)
+        if quant == "near":
+            near_ties(Q)
         m = Stub()
         m.test_users = set(u for u in test if len(test[u]) > 0)
         m.neg_items = {u: [i for i in range(ni) if i not in set(train[u])] for u in range(nu)}
@@ -111,21 +125,24 @@ def g2():
         m.predict = lambda us, its: (P[np.array(us)] * Q[np.array(its)]).sum(1).astype(np.float32)
         res = capture(RM.evaluate, m)
         out.append({"P": P.tolist(), "Q": Q.tolist(), "train": train, "test": {str(u): test[u] for u in test},
-                    "printed": res})
+                    "printed": res, "near_ties": quant == "near"})
     dump("ranking_evaluate.json", out)
 
 
 def g3():
     out = []
-    for seed, quant in [(4, False), (5, True)]:
-        nu, ni, k = 19, 83, 5
-        P, Q, train, test = stub_case(seed, nu, ni, k, quant)
+    for seed, quant, k in [(4, False, 5), (5, True, 5), (6, "near", 40), (8, "near", 150)]:
+        nu, ni = 19, 83
+        P, Q, train, test = stub_case(seed, nu, ni, k, quant is True)
         rng = np.random.default_rng(seed + 100)
         S = rng.standard_normal((nu, k)).astype(np.float32)
         X = rng.standard_normal((ni, k)).astype(np.float32)
         bias = rng.standard_normal(ni).astype(np.float32)
-        if quant:
+        if quant is True:
             S, X = np.round(S * 2) / 2, np.round(X * 2) / 2
+        if quant == "near":
+            near_ties(X, Q)
+            bias[1::2] = bias[0:-1:2]
         test1 = {u: (test[u][:1] if test[u] else []) for u in test}
         m = Stub()
         m.test_users = [u for u in range(nu)]                # evaluate1 indexes results[u] by user id
@@ -154,6 +171,7 @@ def g3():
         res3 = capture(SM.evaluate, m3)
         out.append({"P": P.tolist(), "S": S.tolist(), "X": X.tolist(), "Q": Q.tolist(), "bias": bias.tolist(),
                     "train": train, "test": {str(u): test1[u] for u in test1}, "alpha": 0.2,
+                    "near_ties": quant == "near",
                     "evaluate1": res1, "evaluate_caser": res2, "evaluate": res3})
     dump("seq_evaluate.json", out)
 
