@@ -14,7 +14,8 @@ class OptParams(C.Structure):
     """dr_opt_params (include/deeprec_amd.h)."""
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("alpha", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("rho", C.c_float), ("momentum", C.c_float),
-                ("reg", C.c_float), ("reg_mode", C.c_int32), ("alpha_dev", C.c_void_p)]
+                ("reg", C.c_float), ("reg_mode", C.c_int32), ("alpha_dev", C.c_void_p),
+                ("reg_dev", C.c_void_p)]
 
 
 _p = C.c_void_p

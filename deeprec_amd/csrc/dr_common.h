@@ -155,10 +155,12 @@ struct OptP {
     int kind, reg_mode;
     float lr, alpha, omb1, omb2, eps, omrho, momentum, reg;
     const float* alpha_dev;
+    const float* reg_dev;
 };
 // kernels call this once at entry: a device-resident alpha (graph replay) overrides the host value
 __device__ __forceinline__ OptP resolve(OptP o) {
     if (o.alpha_dev) o.alpha = *o.alpha_dev;
+    if (o.reg_dev) o.reg = *o.reg_dev;
     return o;
 }
 static inline OptP make_optp(const dr_opt_params* o) {
@@ -174,6 +176,7 @@ static inline OptP make_optp(const dr_opt_params* o) {
     p.momentum = o->momentum;
     p.reg = o->reg;
     p.alpha_dev = o->alpha_dev;
+    p.reg_dev = o->reg_dev;
     return p;
 }
 

@@ -56,10 +56,12 @@ def _i32(t, name):
 
 
 def opt_params(kind, lr=0.0, alpha=0.0, beta1=0.9, beta2=0.999, eps=1e-8, rho=0.9, momentum=0.0, reg=0.0,
-               reg_mode=REG_TOUCHED, alpha_dev=None):
-    """alpha_dev: optional device float tensor (1 element) overriding alpha at kernel run time (graph replay)."""
+               reg_mode=REG_TOUCHED, alpha_dev=None, reg_dev=None):
+    """alpha_dev / reg_dev: optional device float tensors (1 element) overriding alpha / reg at kernel run time (graph
+    replay; coefficients computed on the device).  The caller keeps them alive until the kernels have run."""
     return OptParams(kind, lr, alpha, beta1, beta2, eps, rho, momentum, reg, reg_mode,
-                     alpha_dev.data_ptr() if alpha_dev is not None else None)
+                     alpha_dev.data_ptr() if alpha_dev is not None else None,
+                     reg_dev.data_ptr() if reg_dev is not None else None)
 
 
 class AdamState:

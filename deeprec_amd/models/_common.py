@@ -129,14 +129,37 @@ class GraphedStep:
     comes into being); call 2 copies its arguments into static buffers, captures `fn` on them (capture executes
     nothing) and replays; later calls copy and replay.  Same kernels on the same data in the same order, so results
     are bit-identical to the eager loop.  Only for steps whose host side is stateless from step to step (Adagrad /
-    RMSProp / SGD; Adam with TFOptimizer.device_alpha(), which moves the bias correction to the device).  Falls back
-    to eager for good when the shapes change, capture fails, or DR_NO_GRAPH is set."""
+    RMSProp / SGD; Adam with TFOptimizer.device_alpha(), which moves the bias correction to the device).
 
-    def __init__(self, fn):
+    A capture that fails is not hidden: the exception is kept in `capture_error` and reported with a warning, the host
+    state the aborted capture touched (the optimizer's step counter and beta powers, the tables' recorded lookup
+    gradients, which point at capture-pool memory that never executed) is put back, and the step is run eagerly from
+    then on.  `owner` is the model whose TFOptimizer / Table attributes are guarded that way.  `replays` counts graph
+    launches (tests assert that the models meant to replay really do).  DR_NO_GRAPH=1 keeps everything eager."""
+
+    def __init__(self, fn, owner=None):
         import os
-        self.fn, self.graph, self.calls = fn, None, 0
+        self.fn, self.graph, self.calls, self.replays = fn, None, 0, 0
+        self.owner = owner if owner is not None else getattr(fn, "__self__", None)
         self.off = os.environ.get("DR_NO_GRAPH") is not None
+        self.capture_error = None
         self.static, self.out = None, None
+
+    def _host_state(self):
+        opts, tables = [], []
+        for v in (vars(self.owner).values() if self.owner is not None else ()):
+            if isinstance(v, TFOptimizer):
+                opts.append((v, (v.step_count, v._b1p, v._b2p)))
+            elif isinstance(v, Table):
+                tables.append((v, list(v.pending), list(v._deferred)))
+        return opts, tables
+
+    @staticmethod
+    def _restore(state):
+        for o, (n, b1, b2) in state[0]:
+            o.step_count, o._b1p, o._b2p = n, b1, b2
+        for t, pend, deferred in state[1]:
+            t.pending, t._deferred = pend, deferred
 
     def __call__(self, *tensors):
         if self.off:
@@ -145,6 +168,7 @@ class GraphedStep:
         if self.calls == 1:
             return self.fn(*tensors)
         if self.graph is None:
+            state = self._host_state()
             try:
                 self.static = [t.clone() for t in tensors]
                 torch.cuda.synchronize()
@@ -152,9 +176,14 @@ class GraphedStep:
                 with torch.cuda.graph(g):
                     self.out = self.fn(*self.static)
                 self.graph = g
-            except Exception:
+            except Exception as e:                      # noqa: BLE001 -- reported, not swallowed
+                import warnings
+                self.capture_error = e
                 self.off = True
+                self._restore(state)
                 torch.cuda.synchronize()
+                warnings.warn("GraphedStep: hipGraph capture of %s failed (%s: %s); running eagerly"
+                              % (getattr(self.fn, "__qualname__", self.fn), type(e).__name__, e), RuntimeWarning)
                 return self.fn(*tensors)
         elif any(s.shape != t.shape or s.dtype != t.dtype for s, t in zip(self.static, tensors)):
             self.off = True
@@ -163,6 +192,7 @@ class GraphedStep:
             for s, t in zip(self.static, tensors):
                 s.copy_(t)
         self.graph.replay()
+        self.replays += 1
         return self.out
 
 
@@ -189,8 +219,16 @@ class TFOptimizer:
         self._dev = None            # K.AdamState: the bias-corrected step size lives on the device (device_alpha())
 
     def slots_for(self, t):
+        """Optimizer slots of parameter tensor `t`.  Keyed by the tensor's address, and the entry keeps `t` alive: its
+        memory cannot be freed and handed to another tensor while the entry exists, so an address never names two
+        parameters.  A parameter that is REPLACED (not updated in place) must be released with drop(old) -- Table.w's
+        setter and load_checkpoint() copy in place instead, which keeps the slots attached."""
         key = t.data_ptr()
-        if key not in self.slots:
+        ent = self.slots.get(key)
+        if ent is not None and ent[0].shape != t.shape:
+            raise RuntimeError("TFOptimizer: a parameter of shape %s now lives where one of shape %s was registered; "
+                               "call drop(old) when replacing a parameter tensor" % (tuple(t.shape), tuple(ent[0].shape)))
+        if ent is None:
             n = self.NSLOTS[self.kind]
             if self.kind == "adagrad":
                 s = [torch.full_like(t, self.acc0)]
@@ -198,8 +236,24 @@ class TFOptimizer:
                 s = [torch.ones_like(t), torch.zeros_like(t)]      # [TF-ext] RMSProp ms starts at 1, mom at 0
             else:
                 s = [torch.zeros_like(t) for _ in range(n)]
-            self.slots[key] = (s + [None, None])[:2]
-        return self.slots[key]
+            ent = (t, (s + [None, None])[:2])
+            self.slots[key] = ent
+        return ent[1]
+
+    def drop(self, t):
+        """Forget the slots of a parameter tensor that is being replaced (frees 1-2x its size)."""
+        self.slots.pop(t.data_ptr(), None)
+
+    def state(self):
+        """Step counter and beta powers (what TensorFlow keeps in beta1_power / beta2_power) for checkpoints."""
+        return [float(self.step_count), float(self._b1p), float(self._b2p)]
+
+    def set_state(self, st):
+        self.step_count = int(st[0])
+        self._b1p, self._b2p = np.float32(st[1]), np.float32(st[2])
+        if self._dev is not None:
+            self._dev.state[0] = float(self._b1p)
+            self._dev.state[1] = float(self._b2p)
 
     def device_alpha(self, device):
         """Adam only: keep beta1^t, beta2^t and alpha_t on the device (dr_adam_tick_f32: the same fp32 running products
@@ -220,22 +274,28 @@ class TFOptimizer:
             self._dev.tick()
 
     def params(self, reg, reg_mode):
+        """reg: a number, or a 1-element float32 DEVICE tensor (a coefficient computed on the device, e.g. NNMF's
+        reg_rate / ||W||: dr_opt_params.reg_dev) -- the caller keeps that tensor alive until the kernels have run."""
         alpha = 0.0
         if self.kind == "adam":
             alpha = float(np.float32(self.lr) * np.sqrt(np.float32(1) - self._b2p) / (np.float32(1) - self._b1p))
+        reg_dev = reg if isinstance(reg, torch.Tensor) else None
         return K.opt_params(self.KIND[self.kind], lr=self.lr, alpha=alpha, beta1=self.beta1, beta2=self.beta2,
-                            eps=self.eps, rho=self.rho, momentum=self.momentum, reg=float(reg), reg_mode=reg_mode,
-                            alpha_dev=self._dev.alpha if self._dev is not None else None)
+                            eps=self.eps, rho=self.rho, momentum=self.momentum,
+                            reg=0.0 if reg_dev is not None else float(reg), reg_mode=reg_mode,
+                            alpha_dev=self._dev.alpha if self._dev is not None else None, reg_dev=reg_dev)
 
     def apply_dense(self, w, grad, reg=0.0):
         """Whole-tensor application; reg > 0 adds reg*w (tf l2_regularizer / l2_loss terms)."""
         s0, s1 = self.slots_for(w)
-        K.dense_update(w, s0, s1, grad, self.params(reg, K.REG_DENSE if reg else K.REG_NONE))
+        has_reg = isinstance(reg, torch.Tensor) or bool(reg)
+        K.dense_update(w, s0, s1, grad, self.params(reg, K.REG_DENSE if has_reg else K.REG_NONE))
 
     def apply_table(self, table, reg, reg_mode):
         """Apply the recorded lookups' gradients of one embedding table."""
         pend, table.pending = table.pending, []
         if (reg_mode == K.REG_DENSE and not pend and table.lazy and self._dev is None
+                and not isinstance(reg, torch.Tensor)
                 and not (table._w.is_cuda and torch.cuda.is_current_stream_capturing())):
             table.defer(self, self.params(reg, K.REG_DENSE))      # replayed when someone reads table.w
             return
@@ -319,9 +379,14 @@ class Table:
 
     @w.setter
     def w(self, value):
-        if self._deferred:
-            self.flush()
-        self._w = value
+        """New VALUES for the table: copied in place (same shape), so optimizer slots -- keyed by the tensor -- stay
+        attached.  Recorded dense passes of the old values are dropped with them."""
+        self._deferred = []
+        if value is self._w:
+            return
+        if value.shape != self._w.shape:
+            raise ValueError("Table.w: shape %s does not match the table's %s" % (tuple(value.shape), tuple(self._w.shape)))
+        self._w.copy_(value)
 
     def flush(self):
         """Run the recorded dense passes of a lazy table (see __init__)."""
@@ -513,3 +578,71 @@ def normal_(shape, std, device, seed=None):
         seed = int(np.random.randint(0, 2 ** 31 - 1))
     K.init_normal_(w, seed, std)
     return w
+
+
+# ----------------------------------------------------------------------------------------------
+# checkpoints: tables, dense weights, optimizer slots, step counter and beta powers
+# ----------------------------------------------------------------------------------------------
+def checkpoint_tensors(model):
+    """name -> live parameter tensor of a model: its Tables, its dense weights (tensors that require grad, and lists of
+    them), and the plain tensors a class names in CKPT (BPRMF / GMF / MF / CML keep their tables as tensors)."""
+    out = {}
+    names = getattr(model, "CKPT", None)
+    for attr, v in vars(model).items():
+        if names is not None and attr in names and isinstance(v, torch.Tensor):
+            out[attr] = v
+        elif isinstance(v, Table):
+            out[attr] = v.w                                    # flushes a lazy table's recorded passes first
+        elif isinstance(v, torch.Tensor) and v.requires_grad and v.is_leaf:
+            out[attr] = v.data
+        elif isinstance(v, (list, tuple)) and v and all(isinstance(x, torch.Tensor) and x.requires_grad and x.is_leaf
+                                                        for x in v):
+            for i, x in enumerate(v):
+                out["%s.%d" % (attr, i)] = x.data
+    return out
+
+
+def save_checkpoint(model, path):
+    """safetensors file with every parameter, the optimizer slots that exist for it (`<name>.slot<j>`) and the
+    optimizer's step counter / beta powers (`__optimizer__`).  The reference's save() (gmf.py:156-158 and 22 more
+    sites) is tf.train.Saver and never called; nothing here is pickled."""
+    from safetensors.torch import save_file
+    opt = getattr(model, "optimizer", None)
+    d = {}
+    for n, t in checkpoint_tensors(model).items():
+        d[n] = t
+        ent = opt.slots.get(t.data_ptr()) if opt is not None else None
+        if ent is not None:
+            for j, sl in enumerate(ent[1]):
+                if sl is not None:
+                    d["%s.slot%d" % (n, j)] = sl
+    if opt is not None:
+        d["__optimizer__"] = torch.tensor(opt.state(), dtype=torch.float64)
+    save_file({k: v.detach().cpu().contiguous() for k, v in d.items()}, path)
+
+
+def load_checkpoint(model, path):
+    """Inverse of save_checkpoint on a model whose build_network() has run with the same shapes: values are copied IN
+    PLACE into the existing tables / weights / slots (so the optimizer's slot registry stays valid), the step counter
+    and beta powers are restored -- training continues exactly where the saved model stopped."""
+    from safetensors.torch import load_file
+    sl = load_file(path)
+    opt = getattr(model, "optimizer", None)
+    live = checkpoint_tensors(model)
+    missing = [n for n in live if n not in sl]
+    if missing:
+        raise KeyError("checkpoint %s lacks %s" % (path, missing))
+    with torch.no_grad():
+        for n, t in live.items():
+            if tuple(sl[n].shape) != tuple(t.shape):
+                raise ValueError("checkpoint tensor %s has shape %s, the model's %s" % (n, tuple(sl[n].shape), tuple(t.shape)))
+            t.copy_(sl[n])
+            if opt is not None and ("%s.slot0" % n) in sl:
+                for j, s_ in enumerate(opt.slots_for(t)):
+                    if s_ is not None:
+                        s_.copy_(sl["%s.slot%d" % (n, j)])
+    for v in vars(model).values():
+        if isinstance(v, Table):
+            v._deferred, v.pending = [], []
+    if opt is not None and "__optimizer__" in sl:
+        opt.set_state(sl["__optimizer__"].tolist())

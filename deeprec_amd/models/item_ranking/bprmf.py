@@ -20,10 +20,11 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import NegItems, TFOptimizer, device_of, normal_, sample_uniform_negatives, to_dev
+from .._common import (NegItems, TFOptimizer, device_of, normal_, sample_uniform_negatives, to_dev, load_checkpoint, save_checkpoint)
 
 
 class BPRMF(object):
+    CKPT = ("P", "Q")        # parameter tensors written by save() / read by load()
     def __init__(self, num_user, num_item, learning_rate=0.001, reg_rate=0.1, epoch=500, batch_size=1024,
                  verbose=False, t=5, display_step=1000, device=None, reg_mode="dense", sampler="reference"):
         self.num_user = num_user
@@ -126,27 +127,13 @@ class BPRMF(object):
                 self.test()
 
     def save(self, path):
-        """The reference's save() is dead code (tf.train.Saver on a Keras model); tables and optimizer
-        slots are written with safetensors instead."""
-        from safetensors.torch import save_file
-        sl = {"P": self.P, "Q": self.Q}
-        for n, t in (("P", self.P), ("Q", self.Q)):
-            for j, s in enumerate(self.optimizer.slots_for(t)):
-                if s is not None:
-                    sl["%s.slot%d" % (n, j)] = s
-        save_file({k: v.cpu() for k, v in sl.items()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
 
     def load(self, path):
-        """Inverse of save(): tables and optimizer slots from a safetensors file (nothing is unpickled)."""
-        from safetensors.torch import load_file
-        sl = load_file(path)
-        self.P = sl["P"].to(self.device)
-        self.Q = sl["Q"].to(self.device)
-        self.num_factor = self.P.shape[1]
-        for n, t in (("P", self.P), ("Q", self.Q)):
-            for j, s in enumerate(self.optimizer.slots_for(t)):
-                if s is not None and "%s.slot%d" % (n, j) in sl:
-                    s.copy_(sl["%s.slot%d" % (n, j)])
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
 
     def predict(self, user_id, item_id):
         """bprmf.py:168-173 -> np.float32 [N]."""

@@ -12,10 +12,11 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import NegItems, TFOptimizer, device_of, normal_, sample_uniform_negatives, shift_sess, to_dev
+from .._common import (NegItems, TFOptimizer, device_of, normal_, sample_uniform_negatives, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 
 
 class CML(object):
+    CKPT = ("P", "Q")        # parameter tensors written by save() / read by load()
     _keep_rate = 0.98
     _name = "CML"
 
@@ -108,8 +109,13 @@ class CML(object):
                 self.test()
 
     def save(self, path):
-        from safetensors.torch import save_file
-        save_file({"P": self.P.cpu(), "Q": self.Q.cpu()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
 
     def predict(self, user_id, item_id):
         """cml.py:151-153: minus the squared distance (keep_rate 1)."""

@@ -11,10 +11,11 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import NegItems, TFOptimizer, device_of, device_pointwise_epoch, normal_, shift_sess, to_dev
+from .._common import (NegItems, TFOptimizer, device_of, device_pointwise_epoch, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 
 
 class GMF(object):
+    CKPT = ("P", "Q")        # parameter tensors written by save() / read by load()
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.5, reg_rate=0.01, epoch=500, batch_size=256,
                  verbose=False, t=1, display_step=1000, device=None, reg_mode="dense", sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
@@ -124,8 +125,13 @@ class GMF(object):
                 self.test()
 
     def save(self, path):
-        from safetensors.torch import save_file
-        save_file({"P": self.P.cpu(), "Q": self.Q.cpu()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
 
     def predict(self, user_id, item_id):
         """gmf.py:160-161."""

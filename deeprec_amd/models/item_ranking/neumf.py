@@ -16,7 +16,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RankingMetrics import evaluate
-from .._common import GraphedStep, NegItems, TFOptimizer, device_pointwise_epoch, fused_mlp, Table, device_of, normal_, shift_sess, to_dev
+from .._common import (GraphedStep, NegItems, TFOptimizer, device_pointwise_epoch, fused_mlp, Table, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 
 
 class NeuMF(object):
@@ -151,11 +151,13 @@ class NeuMF(object):
                 self.test()
 
     def save(self, path):
-        from safetensors.torch import save_file
-        d = {"P": self.P.w, "Q": self.Q.w, "mlp_P": self.mlp_P.w, "mlp_Q": self.mlp_Q.w}
-        for l, (W, b) in enumerate(zip(self.kernels, self.biases)):
-            d["W%d" % l], d["b%d" % l] = W.data, b.data
-        save_file({k: v.detach().cpu().contiguous() for k, v in d.items()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
 
     def predict(self, user_id, item_id):
         """neumf.py:213-214."""

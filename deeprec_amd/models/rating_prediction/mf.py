@@ -11,10 +11,11 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RatingMetrics import MAE, RMSE
-from .._common import TFOptimizer, device_of, normal_, shift_sess, to_dev
+from .._common import (TFOptimizer, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 
 
 class MF():
+    CKPT = ("P", "Q", "B_U", "B_I")        # parameter tensors written by save() / read by load()
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.001, reg_rate=0.01, epoch=500, batch_size=128,
                  show_time=False, T=2, display_step=1000, device=None, reg_mode="dense"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
@@ -93,8 +94,13 @@ class MF():
                 self.test(test_data)
 
     def save(self, path):
-        from safetensors.torch import save_file
-        save_file({"P": self.P.cpu(), "Q": self.Q.cpu(), "B_U": self.B_U.cpu(), "B_I": self.B_I.cpu()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
 
     def predict(self, user_id, item_id):
         """mf.py:117-118."""

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from ... import kernels as K
-from .._common import GraphedStep, TFOptimizer, Table, fused_mlp, bi_interaction, device_of, normal_, shift_sess, to_dev
+from .._common import (GraphedStep, TFOptimizer, Table, fused_mlp, bi_interaction, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 
 
 class NFM():
@@ -119,10 +119,13 @@ class NFM():
                 self.test(test_data)
 
     def save(self, path):
-        from safetensors.torch import save_file
-        save_file({"feature_embeddings": self.feature_embeddings.w.cpu(), "feature_bias": self.feature_bias.w.cpu(),
-                   "bias": self.bias.detach().reshape(1).cpu(), "pred_weight": self.pred_weight.detach().cpu(),
-                   "W1": self.W1.detach().cpu(), "b1": self.b1.detach().cpu()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
 
     def predict(self, features, drop_mask=None):
         """The reference's predict (nfm.py:148-149) feeds placeholders that do not exist; here it takes

@@ -11,7 +11,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.RatingMetrics import MAE, RMSE
-from .._common import GraphedStep, TFOptimizer, Table, fused_mlp, device_of, normal_, shift_sess, to_dev
+from .._common import (GraphedStep, TFOptimizer, Table, fused_mlp, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 
 
 class NNMF():
@@ -62,9 +62,14 @@ class NNMF():
         o = self.optimizer
         o.begin_step()
         with torch.no_grad():
+            keep = []
             for t in (self.P, self.Q, self.U, self.V):
-                nrm = float(torch.linalg.norm(t.w))               # d/dW reg*||W||_F = reg * W / ||W||_F  (dense)
-                o.apply_table(t, self.reg_rate / nrm if nrm > 0 else 0.0, K.REG_DENSE)
+                # d/dW reg*||W||_F = (reg / ||W||_F) * W (dense).  The coefficient stays on the device
+                # (dr_opt_params.reg_dev): no host read-back in the step, so it can be replayed as a hipGraph
+                nrm = torch.linalg.norm(t.w)
+                coef = torch.where(nrm > 0, self.reg_rate / nrm, torch.zeros_like(nrm)).reshape(1)
+                keep.append(coef)
+                o.apply_table(t, coef, K.REG_DENSE)
             for W, b in zip(self.kernels, self.biases):
                 o.apply_dense(W.data, W.grad, self.reg_rate)
                 o.apply_dense(b.data, b.grad, 0.0)
@@ -106,11 +111,13 @@ class NNMF():
                 self.test(test_data)
 
     def save(self, path):
-        from safetensors.torch import save_file
-        d = {"P": self.P.w, "Q": self.Q.w, "U": self.U.w, "V": self.V.w}
-        for l, (W, b) in enumerate(zip(self.kernels, self.biases)):
-            d["W%d" % l], d["b%d" % l] = W.data, b.data
-        save_file({k: v.detach().cpu().contiguous() for k, v in d.items()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
 
     def predict(self, user_id, item_id):
         u = to_dev(np.asarray(user_id).reshape(-1), torch.int32, self.device)

@@ -13,7 +13,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate1
-from .._common import GraphedStep, TFOptimizer, Table, attn_seq, device_of, normal_, shift_sess, to_dev
+from .._common import (GraphedStep, TFOptimizer, Table, attn_seq, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 from ._seq_common import SeqBase
 
 
@@ -167,7 +167,11 @@ class AttRec(SeqBase):
             return (-self._distance(out, u, it)).reshape(-1).cpu().numpy()
 
     def save(self, path):
-        from safetensors.torch import save_file
-        d = {n: getattr(self, n).w for n in ("P", "V", "Q", "X", "A", "W", "b")}
-        d["linear_project"] = self.linear_project.data
-        save_file({k: v.detach().cpu().contiguous() for k, v in d.items()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
+

@@ -14,7 +14,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate_caser
-from .._common import TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import (TFOptimizer, Table, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 from ._seq_common import SeqBase
 
 
@@ -205,9 +205,11 @@ class Caser(SeqBase):
             return self._score(self._user_emb(seq, u), it).reshape(-1).cpu().numpy()
 
     def save(self, path):
-        from safetensors.torch import save_file
-        d = {n: getattr(self, n).w for n in ("P", "V", "Q", "W", "b")}
-        d.update({"conv_v_w": self.conv_v_w, "conv_v_b": self.conv_v_b, "full_w": self.full_w, "full_b": self.full_b})
-        for i, (w, b) in enumerate(zip(self.conv_h_w, self.conv_h_b), 1):
-            d["conv_h_w%d" % i], d["conv_h_b%d" % i] = w, b
-        save_file({k: v.detach().cpu().contiguous() for k, v in d.items()}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
+

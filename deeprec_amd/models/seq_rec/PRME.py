@@ -10,7 +10,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation import SeqRecMetrics
-from .._common import TFOptimizer, Table, device_of, normal_, shift_sess, to_dev
+from .._common import (TFOptimizer, Table, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 from ._seq_common import SeqBase
 
 
@@ -97,5 +97,11 @@ class PRME(SeqBase):
                 "kind": K.SCORE_TWO_DIST, "alpha": 0.2}
 
     def save(self, path):
-        from safetensors.torch import save_file
-        save_file({n: getattr(self, n).w.cpu() for n in ("P", "V", "Q", "X")}, path)
+        """Tables, dense weights, optimizer slots and step state as safetensors (_common.save_checkpoint); the
+        reference's save() is tf.train.Saver and never called."""
+        save_checkpoint(self, path)
+
+    def load(self, path):
+        """Inverse of save() after build_network(): values copied in place, optimizer state restored."""
+        load_checkpoint(self, path)
+

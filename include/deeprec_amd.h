@@ -71,6 +71,10 @@ typedef struct dr_opt_params {
     const float* alpha_dev; /* optional DEVICE scalar overriding `alpha` (read by the kernels at run time), so a
                                captured hipGraph of a step keeps following Adam's bias correction; see
                                dr_adam_tick_f32.  NULL = use `alpha`.                                  */
+    const float* reg_dev;   /* optional DEVICE scalar overriding `reg` the same way: a coefficient that depends on the
+                               weights themselves -- nnmf.py:82-83 regularises with tf.norm(W), whose gradient is
+                               (reg_rate / ||W||_F) * W -- stays on the device, so the step has no host read-back and
+                               can be captured into a hipGraph.  NULL = use `reg`.                      */
 } dr_opt_params;
 
 const char* dr_last_error(void);
