@@ -139,27 +139,53 @@ def main():
         ws = wss[0]
         side = torch.cuda.Stream(device=device)
         pipelined = not args.no_pipeline
+        # The segment plan of a batch depends on its ids only and is a chain of ~17 short dependent launches: beside the
+        # bandwidth-saturating forward kernel that chain takes ~2x its stand-alone 100 us, longer than the step itself
+        # (0.15 ms), so ONE plan in flight made the step plan-bound (tools/eager_probe.py: 0.222 ms).  DEPTH plans are
+        # kept in flight instead, each on its own stream: batch b + DEPTH is planned while batch b runs.
+        DEPTH = 1 if args.graph else 2
+        sides = [torch.cuda.Stream(device=device) for _ in range(DEPTH)]
+        ev_end = [torch.cuda.Event() for _ in range(nb)]
+        ev_plan = [torch.cuda.Event() for _ in range(nb)]
+        started = {"end": set(), "plan": set()}
 
         def eager_step(b):
-            """One step on resident batch b.  Pipelined: the id lists / segment plans of batch b+1 (they depend on
-            its ids only) are built on a second stream while this step's kernels run; every step still does all of
-            its own work inside the timed region, one batch ahead."""
+            """One step on resident batch b.  Pipelined: the id lists / segment plan of batch b + DEPTH (they depend
+            on its ids only) are built on another stream while this step's kernels run; every step still does all of
+            its own work -- one plan, one step -- inside the timed region."""
             u, i, j = batches[b]
             if adam:
                 adam_state.tick()
             if not pipelined:
                 return K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b])
             cur = torch.cuda.current_stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                K.bpr_plan(args.users, args.items, k, *batches[(b + 1) % nb], wss[(b + 1) % nb])
+            if DEPTH == 1:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    K.bpr_plan(args.users, args.items, k, *batches[(b + 1) % nb], wss[(b + 1) % nb])
+                loss = K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b], planned=True)
+                cur.wait_stream(side)
+                return loss
+            nxt = (b + DEPTH) % nb
+            sd = sides[b % DEPTH]
+            if (b - 1) % nb in started["end"]:
+                sd.wait_event(ev_end[(b - 1) % nb])     # the workspace of batch `nxt` was last read by an earlier step
+            with torch.cuda.stream(sd):
+                K.bpr_plan(args.users, args.items, k, *batches[nxt], wss[nxt])
+                ev_plan[nxt].record(sd)
+                started["plan"].add(nxt)
+            if b in started["plan"]:
+                cur.wait_event(ev_plan[b])
             loss = K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b], planned=True)
-            cur.wait_stream(side)
+            ev_end[b].record(cur)
+            started["end"].add(b)
             return loss
 
         if pipelined:
-            K.bpr_plan(args.users, args.items, k, *batches[0], wss[0])
-            launch = "eager, plans one batch ahead on a second stream"
+            for b in range(DEPTH):
+                K.bpr_plan(args.users, args.items, k, *batches[b], wss[b])
+            launch = ("eager, plans %d batches ahead on %d side streams" % (DEPTH, DEPTH)) if DEPTH > 1 else \
+                "eager, plans one batch ahead on a second stream"
 
         def step(t):
             return eager_step(t % nb)

@@ -19,6 +19,9 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
 int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, int64_t nu, int64_t ni, void* plan,
                    int64_t plan_bytes, int k, hipStream_t st, bool fused);
 const unsigned char* plan_solo_flags(void* plan, int64_t n, int k);
+int bpr_tail_launch(float* P, float* Ps0, float* Ps1, int64_t nu, float* Q, float* Qs0, float* Qs1, int64_t ni, int k,
+                    int64_t B, const float* stash, const float* coefQ, void* plan, int64_t plan_bytes,
+                    const dr_opt_params* opt, hipStream_t st);
 int check_opt(const dr_opt_params* opt, const float* slot0, const float* slot1, const char* who);
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, 
             } else {
 #pragma unroll
                 for (int x = 0; x < V; ++x) pu[x] = qi[x] = qj[x] = 0.0f;
-                if (ok || (vu && (si || sj || need_p_old))) vload<V>(pu, P + iu * k + c * V);
+                if (vu) vload<V>(pu, P + iu * k + c * V);
                 if (ok) {
                     vload<V>(qi, Q + ii * k + c * V);
                     vload<V>(qj, Q + ij * k + c * V);
@@ -238,6 +241,8 @@ __global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, 
                 }
             } else {
                 vstore<V>(stash + b * k + c * V, d);
+                // a shared user row is updated by the tail pass: its item-side contributions read this pre-step copy
+                if (vu && !(si && sj)) vstore<V>(stash + (B + b) * k + c * V, pu);
             }
             if (si) {
                 float tot[V];
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, 
 // The same for k == V * LPR (every lane owns exactly one vector column; k = 128, 64, 32, ...): no column loops and no
 // reload paths, every row and optimizer slot of the sample is requested in one round, and the per-id validity makes
 // the update path uniform (an invalid sample contributes zero rows to its valid solo rows, like the segment path).
+// stash rows [B, 2B): pre-step P[u_b] of samples whose user row is NOT solo (read by their item-side contributions).
 template <int V, int LPR, int KIND>
 __global__ __launch_bounds__(256) void bpr_forward_update_1col_kernel(FusedTables t, const int32_t* __restrict__ u,
                                                                       const int32_t* __restrict__ i,
@@ -349,6 +355,8 @@ __global__ __launch_bounds__(256) void bpr_forward_update_1col_kernel(FusedTable
             apply_row_loaded<V, KIND>(t.p, (uint32_t)iu, lane, tot, pu, mu, vu2);
         } else {
             vstore<V>(stash + b * k + lane * V, d);
+            // a shared user row is updated by the tail pass: its item-side contributions read this pre-step copy
+            if (vu && !(si && sj)) vstore<V>(stash + (B + b) * k + lane * V, pu);
         }
     }
 }
@@ -699,9 +707,11 @@ static int bpr_forward_update(float* P, float* Ps0, float* Ps1, int64_t num_user
     t.q.table = Q; t.q.slot0 = Qs0; t.q.slot1 = Qs1; t.q.rows = num_item;
     RowShape s = row_shape(k);
     bool ok = false;
+    static const int64_t fwd_grid = getenv("DR_FWD_GRID") ? atoll(getenv("DR_FWD_GRID")) : 0;  // experiment knob
 #define DR_F(V_, L_)                                                                                                  \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                            \
-        const int64_t wb_ = (B + 256 / L_ - 1) / (256 / L_);                                                           \
+        int64_t wb_ = (B + 256 / L_ - 1) / (256 / L_);                                                                 \
+        if (fwd_grid > 0 && wb_ > fwd_grid) wb_ = fwd_grid;                                                           \
         if (k == V_ * L_ && opt->kind == DR_OPT_ADAM)                                                                 \
             DR_LAUNCH_NAMED("bpr_forward_update_kernel", (bpr_forward_update_1col_kernel<V_, L_, DR_OPT_ADAM>),       \
                             dim3(grid_resident(bpr_forward_update_1col_kernel<V_, L_, DR_OPT_ADAM>, wb_)), dim3(256),  \
@@ -802,7 +812,15 @@ static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_use
         }
         if (mode == 1) return DR_OK;
     }
-    if (any) {
+    static const bool no_tail = getenv("DR_NO_TAIL") != nullptr;
+    if (any && fused && mode == 2 && !no_tail) {
+        // every row with two or more contributions, both tables, one launch (bpr_tail_kernel): rows of the two tables
+        // are disjoint, Q-side sources are pre-step P rows (in place for non-solo users, the stash copy for solo ones)
+        // and P-side sources are stash rows, none of which this launch writes
+        rc = bpr_tail_launch(P, Pslot0, Pslot1, num_user, Q, Qslot0, Qslot1, num_item, k, B, stash, coefQ,
+                             base + L.planA, L.plan_bytesA, opt, st);
+        if (rc != DR_OK) return rc;
+    } else if (any) {
         // one combined plan: segments below the split are P rows (contributions = stash rows b), the others Q
         // rows (key - num_user; contributions (+-g_b) * P[u_b]).  Q first: its gradient needs the pre-step P rows.
         if (side) DR_HIP(hipStreamWaitEvent(st, side->q_ready, 0));

@@ -20,7 +20,7 @@ namespace dr {
 // ---------------------------------------------------------------------------------------
 struct PlanLayout {
     int64_t hdr, keys_in, keys_out, vals_in, vals_out, flags, segidx, uniq, seg_start, temp, temp_bytes, total;
-    int64_t long_seg, long_cb, part_owner, partials, partial_rows, msrc, mcoef, solo;
+    int64_t long_seg, long_cb, part_owner, partials, partial_rows, msrc, mcoef, solo, multi, long_cnt;
 };
 
 // Segments with more than LONG_SEG contributions ("long": anything beyond the few-duplicates common case) are
@@ -74,6 +74,8 @@ static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
     L->msrc = take(nn * 4);
     L->mcoef = take(nn * 4);
     L->solo = take(nn);  // one byte per ORIGINAL position: its segment has exactly one contribution (BPR plans)
+    L->multi = take((nn / 2 + 1) * 4);   // segments with 2 .. LONG_SEG contributions (arbitrary order), count in hdr[4]
+    L->long_cnt = take(max_long * 4);    // blocks of a long segment summed so far (bpr_tail_kernel), zero between uses
     L->partials = take(L->partial_rows * (int64_t)(k_max > 0 ? k_max : 1) * 4);
     L->total = off;
     return 0;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void plan_keys_kernel(const IdT* __restrict__ 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr[1] = 0;  // number of long segments
         hdr[2] = 0;  // partial rows handed out
+        hdr[4] = 0;  // number of segments with 2 .. LONG_SEG contributions
     }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         int64_t id = (int64_t)ids[e];
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(256) void plan_keys_bpr_kernel(const int32_t* __res
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr[1] = 0;
         hdr[2] = 0;
+        hdr[4] = 0;
     }
     const uint32_t sentinel = (uint32_t)(nu + ni);
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 3 * B; e += (int64_t)gridDim.x * 256) {
@@ -174,15 +178,17 @@ __global__ __launch_bounds__(256) void bpr_meta_kernel(const int32_t* __restrict
     }
 }
 
-// second pass of the fused variant (needs every solo flag): Q-side contributions of solo users read stash row x
+// second pass of the fused variant (needs every solo flag): Q-side contributions read the stash copy of the user row
 __global__ __launch_bounds__(256) void bpr_meta_solo_kernel(const int32_t* __restrict__ sorted_pos, int64_t B, int64_t nu,
                                                             const unsigned char* __restrict__ solo,
                                                             int32_t* __restrict__ msrc) {
     for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < 3 * B; y += (int64_t)gridDim.x * 256) {
         const int p = sorted_pos[y];
         if (p >= B) {
+            // the pre-step user row of sample x: stash row x when the user row is solo, stash row B + x otherwise
+            // (the forward kernel leaves it there) -- never P in place, so the item side may run beside the user side
             const int64_t x = (p - B) % B;
-            if (msrc[y] >= 0 && solo[x]) msrc[y] = (int32_t)(nu + x);
+            if (msrc[y] >= 0) msrc[y] = (int32_t)(nu + (solo[x] ? x : B + x));
         }
     }
 }
@@ -192,6 +198,7 @@ __global__ void plan_empty_kernel(int32_t* hdr, int32_t* seg_start) {
     hdr[1] = 0;
     hdr[2] = 0;
     hdr[3] = 0;
+    hdr[4] = 0;
     seg_start[0] = 0;
 }
 
@@ -199,8 +206,10 @@ __global__ void plan_empty_kernel(int32_t* hdr, int32_t* seg_start) {
 // arbitrary; it never influences a result)
 __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restrict__ seg_start, int32_t* __restrict__ hdr,
                                                         int32_t* __restrict__ long_seg, int32_t* __restrict__ long_cb,
-                                                        int32_t* __restrict__ part_owner, int64_t n) {
+                                                        int32_t* __restrict__ part_owner, int32_t* __restrict__ multi,
+                                                        int32_t* __restrict__ long_cnt, int64_t n) {
     const int nseg = hdr[0];
+    const int lane = threadIdx.x & 63;
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * 256) {
         const int len = seg_start[s + 1] - seg_start[s];
         if (len > LONG_SEG) {
@@ -209,7 +218,19 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
             const int cb = atomicAdd(&hdr[2], nch);
             long_seg[l] = (int32_t)s;
             long_cb[l] = cb;
+            long_cnt[l] = 0;
             for (int c = 0; c < nch; ++c) part_owner[cb + c] = l;
+        }
+        // one atomic per wavefront for the (many) rows with 2 .. LONG_SEG contributions: 20 k same-address atomics
+        // made this kernel 22 us instead of 9
+        const bool is_multi = len >= 2 && len <= LONG_SEG;
+        const unsigned long long m = __ballot(is_multi);
+        if (is_multi) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&hdr[4], __popcll(m));
+            base = __shfl(base, leader, 64);
+            multi[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
         }
     }
 }
@@ -228,7 +249,9 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
                                                               int32_t* __restrict__ uniq, int32_t* __restrict__ seg_start,
                                                               int32_t* __restrict__ hdr, int32_t* __restrict__ long_seg,
                                                               int32_t* __restrict__ long_cb,
-                                                              int32_t* __restrict__ part_owner) {
+                                                              int32_t* __restrict__ part_owner,
+                                                              int32_t* __restrict__ multi,
+                                                              int32_t* __restrict__ long_cnt) {
     using Sort = rocprim::block_radix_sort<uint32_t, SMALL_T, SMALL_IPT, int32_t>;
     using Scan = rocprim::block_scan<int, SMALL_T>;
     __shared__ union {
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
         typename Scan::storage_type scan;
     } tmp;
     __shared__ uint32_t sk[SMALL_T * SMALL_IPT];
-    __shared__ int sh_split, sh_nlong, sh_parts;
+    __shared__ int sh_split, sh_nlong, sh_parts, sh_multi;
     const int tid = threadIdx.x;
     // padding keys carry the largest value the sorted bits can hold and positions >= n: the sort is stable, so
     // they end up behind every real entry
@@ -262,6 +285,7 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
     if (tid == 0) {
         sh_nlong = 0;
         sh_parts = 0;
+        sh_multi = 0;
     }
     __syncthreads();
     int flag[SMALL_IPT], cnt = 0;
@@ -296,7 +320,10 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
             const int cb = atomicAdd(&sh_parts, nch);
             long_seg[l] = s;
             long_cb[l] = cb;
+            long_cnt[l] = 0;
             for (int c = 0; c < nch; ++c) part_owner[cb + c] = l;
+        } else if (len >= 2) {
+            multi[atomicAdd(&sh_multi, 1)] = s;
         }
     }
     __syncthreads();
@@ -305,6 +332,7 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
         hdr[1] = sh_nlong;
         hdr[2] = sh_parts;
         hdr[3] = sh_split;
+        hdr[4] = sh_multi;
     }
 }
 
@@ -553,6 +581,156 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
     }
 }
 
+
+// ---- the fused BPR step's whole duplicate-row tail in ONE launch --------------------------------------------------
+// After the fused forward kernel has applied every single-contribution row, what is left of a batch is (C4: per 65 536
+// samples) ~20 k rows with 2 .. LONG_SEG contributions and a few hundred Zipf-head rows with more, spread over both
+// tables.  As separate launches (short / long partial / long combine, per table) that was six kernels of 8 - 23 us,
+// each mostly a walk over the 140 k-entry segment table and launch ramp; here one grid handles
+//   work ids [0, hdr[2]):           one DR_SEG_CHUNK block of a long segment -> its partial row
+//   work ids [hdr[2], + hdr[4]):    one row of the plan's `multi` list (2 .. LONG_SEG contributions)
+// of both tables (segments below hdr[3] are user rows, the others item rows); bpr_tail_combine_kernel then adds each
+// long segment's partial rows in block order and applies the row, for both tables.  (Combining inside the first launch
+// -- last finished block of a segment, device-scope counter -- was measured: the two device-scope fences per block
+// write back and invalidate a whole L2 each on this multi-XCD part, 101 us for the launch.)  Same blocked position
+// order, the same operations per row as seg_update_kernel / seg_long_*_kernel: bit-identical results.
+struct TailArgs {
+    SegArgs p, q;
+    const int32_t* multi;
+    int32_t* long_cnt;
+};
+
+template <int V, int LPR, int KIND>
+__global__ __launch_bounds__(256) void bpr_tail_kernel(TailArgs t) {
+    t.p.opt = resolve(t.p.opt);
+    t.q.opt = t.p.opt;
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int cpr = t.p.k / V;
+    const int k = t.p.k;
+    const int nparts = t.p.hdr[2], nmulti = t.p.hdr[4], split = t.p.hdr[3];
+    const int total = nparts + nmulti;
+    for (int w = blockIdx.x * SPB + sub; w < total; w += gridDim.x * SPB) {
+        if (w < nparts) {
+            const int l = t.p.part_owner[w];
+            const int s = t.p.long_seg[l];
+            const SegArgs& a = (s < split) ? t.p : t.q;
+            const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
+            if ((int64_t)r >= a.rows) continue;  // the sentinel segment of out-of-range ids
+            const int cb = a.long_cb[l];
+            const int b = a.seg_start[s], e = a.seg_start[s + 1];
+            const int c0 = b + (w - cb) * DR_SEG_CHUNK;
+            const int c1 = (c0 + DR_SEG_CHUNK < e) ? c0 + DR_SEG_CHUNK : e;
+            for (int c = lane; c < cpr; c += LPR) {
+                float acc[V];
+                block_sum<V, 16>(a, c0, c1, c, acc);
+                vstore<V>(a.partials + (int64_t)w * k + c * V, acc);
+            }
+        } else {
+            const int s = t.multi[w - nparts];
+            const SegArgs& a = (s < split) ? t.p : t.q;
+            const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
+            if ((int64_t)r >= a.rows) continue;
+            const int b = a.seg_start[s];
+            const int len = a.seg_start[s + 1] - b;  // 2 .. LONG_SEG
+            int si[4];
+            float cf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                si[q] = -1;
+                cf[q] = 1.0f;
+                if (q < len) {
+                    si[q] = a.msrc[b + q];
+                    if (a.coef && si[q] >= 0) cf[q] = a.coef[a.spos[b + q] - a.pos_lo];
+                }
+            }
+            for (int c = lane; c < cpr; c += LPR) {
+                float v[4][V], tot[V];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (si[q] >= 0) vload<V>(v[q], seg_src_row(a, si[q]) + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (si[q] >= 0) {
+#pragma unroll
+                        for (int x = 0; x < V; ++x) tot[x] = tot[x] + (a.coef ? cf[q] * v[q][x] : v[q][x]);
+                    }
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = 0.0f + tot[x];
+                apply_row<V, KIND>(a, r, c, tot);
+            }
+        }
+    }
+}
+
+template <int V, int LPR, int KIND>
+__global__ __launch_bounds__(256) void bpr_tail_combine_kernel(TailArgs t) {
+    t.p.opt = resolve(t.p.opt);
+    t.q.opt = t.p.opt;
+    constexpr int SPB = 256 / LPR;
+    const int sub = threadIdx.x / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int k = t.p.k;
+    const int cpr = k / V;
+    const int nlong = t.p.hdr[1], split = t.p.hdr[3];
+    for (int l = blockIdx.x * SPB + sub; l < nlong; l += gridDim.x * SPB) {
+        const int s = t.p.long_seg[l];
+        const SegArgs& a = (s < split) ? t.p : t.q;
+        const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
+        if ((int64_t)r >= a.rows) continue;
+        const int nch = (a.seg_start[s + 1] - a.seg_start[s] + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK;
+        const float* part = a.partials + (int64_t)a.long_cb[l] * k;
+        for (int c = lane; c < cpr; c += LPR) {
+            float tot[V];
+#pragma unroll
+            for (int x = 0; x < V; ++x) tot[x] = 0.0f;
+            int ch = 0;
+            for (; ch + 8 <= nch; ch += 8) {
+                float v[8][V];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vload<V>(v[q], part + (int64_t)(ch + q) * k + c * V);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[q][x];
+                }
+            }
+            for (; ch < nch; ++ch) {
+                float v[V];
+                vload<V>(v, part + (int64_t)ch * k + c * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[x];
+            }
+            apply_row<V, KIND>(a, r, c, tot);
+        }
+    }
+}
+
+template <int V, int LPR>
+static void launch_tail(const TailArgs& t, int64_t n, hipStream_t st) {
+    constexpr int SPB = 256 / LPR;
+    // work items <= n / DR_SEG_CHUNK + n / LONG_SEG (long blocks) + n / 2 (multi rows)
+    const int64_t items = n / DR_SEG_CHUNK + n / LONG_SEG + n / 2 + 1;
+    const int64_t blocks = (items + SPB - 1) / SPB;
+    const int cgrid = grid_for(n / LONG_SEG + 1, 1, SPB);
+    if (t.p.kind == DR_OPT_ADAM) {
+        DR_LAUNCH_NAMED("bpr_tail_kernel", (bpr_tail_kernel<V, LPR, DR_OPT_ADAM>),
+                        dim3(grid_resident(bpr_tail_kernel<V, LPR, DR_OPT_ADAM>, blocks)), dim3(256), 0, st, t);
+        if (n > LONG_SEG)
+            DR_LAUNCH_NAMED("bpr_tail_combine_kernel", (bpr_tail_combine_kernel<V, LPR, DR_OPT_ADAM>), dim3(cgrid), dim3(256),
+                            0, st, t);
+    } else {
+        DR_LAUNCH_NAMED("bpr_tail_kernel", (bpr_tail_kernel<V, LPR, KIND_ANY>),
+                        dim3(grid_resident(bpr_tail_kernel<V, LPR, KIND_ANY>, blocks)), dim3(256), 0, st, t);
+        if (n > LONG_SEG)
+            DR_LAUNCH_NAMED("bpr_tail_combine_kernel", (bpr_tail_combine_kernel<V, LPR, KIND_ANY>), dim3(cgrid), dim3(256), 0,
+                            st, t);
+    }
+}
+
 template <int V, int LPR, int KIND>
 static void launch_short_k(const SegArgs& a, int grid, hipStream_t st) {
     // grid: blocks of work; launched with at most the number of blocks the device holds at once (no partial last wave)
@@ -721,11 +899,13 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
         if (n <= 256 * SMALL_IPT)
             DR_LAUNCH(plan_small_kernel<256>, dim3(1), dim3(256), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
                       split_key, keys_out, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
-                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner));
+                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int32_t*)(base + L.multi),
+                      (int32_t*)(base + L.long_cnt));
         else
             DR_LAUNCH(plan_small_kernel<1024>, dim3(1), dim3(1024), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
                       split_key, keys_out, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
-                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner));
+                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int32_t*)(base + L.multi),
+                      (int32_t*)(base + L.long_cnt));
         DR_CHECK_LAUNCH("plan_small_kernel");
         return DR_OK;
     }
@@ -741,9 +921,10 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
     DR_LAUNCH(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start, hdr,
               split_key);
     DR_CHECK_LAUNCH("plan_finalize_kernel");
-    if (n > LONG_SEG) {
+    if (n >= 2) {
         DR_LAUNCH(plan_long_kernel, dim3(grid), dim3(256), 0, st, seg_start, hdr, (int32_t*)(base + L.long_seg),
-                  (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), n);
+                  (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int32_t*)(base + L.multi),
+                  (int32_t*)(base + L.long_cnt), n);
         DR_CHECK_LAUNCH("plan_long_kernel");
     }
     return DR_OK;
@@ -755,7 +936,7 @@ int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t
                    int64_t plan_bytes, int k, hipStream_t st, bool fused) {
     const int64_t n = 3 * B;
     DR_REQUIRE(n < (1ll << 31) - 1 && nu + ni < (1ll << 32) - 2, "bpr plan: batch / tables too large for 32-bit keys");
-    DR_REQUIRE(!fused || nu + B < (1ll << 31) - 1, "bpr plan: num_user + B exceeds 31 bits");
+    DR_REQUIRE(!fused || nu + 2 * B < (1ll << 31) - 1, "bpr plan: num_user + 2 B exceeds 31 bits");
     PlanLayout L;
     if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
     if (plan_bytes < L.total)
@@ -874,17 +1055,10 @@ const unsigned char* plan_solo_flags(void* plan, int64_t n, int k) {
 
 // n: contributions the plan was built for; n_table: those of them that belong to this table (grid sizing);
 // sel: which part of a combined two-table plan this launch owns ({0,0,0} = an ordinary single-table plan)
-int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
-               const int32_t* src_idx, const float* coef, int64_t n, void* plan, int64_t plan_bytes, int kind,
-               const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel, int64_t n_table, const float* src2,
-               bool skip_single) {
-    PlanLayout L;
-    if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
-    if (plan_bytes < L.total)
-        DR_FAIL(DR_ERR_WORKSPACE, "segment kernel: plan workspace %lld < dr_segment_plan_bytes(n=%lld, k=%d) = %lld",
-                (long long)plan_bytes, (long long)n, k, (long long)L.total);
-    char* base = (char*)plan;
-    SegArgs a;
+static int seg_fill(SegArgs& a, const PlanLayout& L, char* base, float* table, float* slot0, float* slot1, int64_t rows,
+                    int k, const float* src, int64_t src_rows, const int32_t* src_idx, const float* coef, int64_t n,
+                    void* plan, int kind, const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel,
+                    const float* src2, bool skip_single) {
     a.table = table;
     a.slot0 = slot0;
     a.slot1 = slot1;
@@ -905,10 +1079,8 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
     } else if (src_idx == nullptr && src_rows >= n) {
         a.msrc = sorted_pos;  // contribution e reads row e: the sorted positions are the source rows
     } else {
-        if (!meta_ready) {
-            int rc = seg_meta(plan, n, src_idx, src_rows, st);
-            if (rc != DR_OK) return rc;
-        }
+        int rc = seg_meta(plan, n, src_idx, src_rows, st);
+        if (rc != DR_OK) return rc;
         a.msrc = (const int32_t*)(base + L.msrc);
     }
     a.uniq = (const int32_t*)(base + L.uniq);
@@ -921,8 +1093,60 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
     a.kind = kind;
     if (opt) a.opt = make_optp(opt);
     else memset(&a.opt, 0, sizeof(a.opt));
+    return DR_OK;
+}
+
+int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, const float* src, int64_t src_rows,
+               const int32_t* src_idx, const float* coef, int64_t n, void* plan, int64_t plan_bytes, int kind,
+               const dr_opt_params* opt, hipStream_t st, bool meta_ready, SegSel sel, int64_t n_table, const float* src2,
+               bool skip_single) {
+    PlanLayout L;
+    if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "segment kernel: plan workspace %lld < dr_segment_plan_bytes(n=%lld, k=%d) = %lld",
+                (long long)plan_bytes, (long long)n, k, (long long)L.total);
+    SegArgs a;
+    int rc = seg_fill(a, L, (char*)plan, table, slot0, slot1, rows, k, src, src_rows, src_idx, coef, n, plan, kind, opt, st,
+                      meta_ready, sel, src2, skip_single);
+    if (rc != DR_OK) return rc;
     if (dispatch_seg(a, n_table > 0 ? n_table : n, st) != 0) DR_FAIL(DR_ERR_ARG, "segment kernel: unsupported k=%d", k);
     DR_CHECK_LAUNCH("seg_update_kernel");
+    return DR_OK;
+}
+
+// The fused BPR step's tail (bpr_tail_kernel): every row with two or more contributions, of both tables, one launch.
+// The combined plan of the batch (plan_build_bpr, fused) must be in `plan`; stash / coefQ as in bpr_step_impl.
+int bpr_tail_launch(float* P, float* Ps0, float* Ps1, int64_t nu, float* Q, float* Qs0, float* Qs1, int64_t ni, int k,
+                    int64_t B, const float* stash, const float* coefQ, void* plan, int64_t plan_bytes,
+                    const dr_opt_params* opt, hipStream_t st) {
+    const int64_t n = 3 * B;
+    PlanLayout L;
+    if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "bpr tail: plan workspace %lld < required %lld", (long long)plan_bytes, (long long)L.total);
+    char* base = (char*)plan;
+    TailArgs t;
+    int rc = seg_fill(t.q, L, base, Q, Qs0, Qs1, ni, k, P, nu, nullptr, coefQ, n, plan, opt->kind, opt, st, true,
+                      SegSel{(uint32_t)nu, 2, (int)B}, stash, true);
+    if (rc != DR_OK) return rc;
+    rc = seg_fill(t.p, L, base, P, Ps0, Ps1, nu, k, stash, B, nullptr, nullptr, n, plan, opt->kind, opt, st, true,
+                  SegSel{0, 1, 0}, nullptr, true);
+    if (rc != DR_OK) return rc;
+    t.multi = (const int32_t*)(base + L.multi);
+    t.long_cnt = (int32_t*)(base + L.long_cnt);
+    RowShape s = row_shape(k);
+    bool ok = false;
+#define DR_T(V_, L_)                          \
+    if (!ok && s.V == V_ && s.LPR == L_) {    \
+        launch_tail<V_, L_>(t, n, st);        \
+        ok = true;                            \
+    }
+    DR_T(4, 1) DR_T(4, 2) DR_T(4, 4) DR_T(4, 8) DR_T(4, 16) DR_T(4, 32) DR_T(4, 64)
+    DR_T(2, 1) DR_T(2, 2) DR_T(2, 4) DR_T(2, 8) DR_T(2, 16) DR_T(2, 32) DR_T(2, 64)
+    DR_T(1, 1) DR_T(1, 2) DR_T(1, 4) DR_T(1, 8) DR_T(1, 16) DR_T(1, 32) DR_T(1, 64)
+#undef DR_T
+    DR_REQUIRE(ok, "bpr tail: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("bpr_tail_kernel");
     return DR_OK;
 }
 

@@ -24,6 +24,7 @@ nb = len(batches)
 wss = [K.StepWorkspace(args.batch, args.k, args.users, args.items, K.REG_TOUCHED, dev) for _ in range(nb)]
 side = torch.cuda.Stream(device=dev)
 mode = os.environ.get("MODE", "plan_first")
+sides = [torch.cuda.Stream(device=dev) for _ in range(3)]
 ev_end = [None] * nb
 ev_plan = [None] * nb
 
@@ -54,6 +55,22 @@ def step(b):
             e = torch.cuda.Event()
             e.record(side)
             ev_plan[(b + 2) % nb] = e
+        if ev_plan[b] is not None:
+            cur.wait_event(ev_plan[b])
+        K.bpr_step(P, Q, sP, sQ, u, i, j, opt, wss[b], planned=True)
+        e = torch.cuda.Event()
+        e.record(cur)
+        ev_end[b] = e
+    elif mode in ("depth2x2", "depth3x3"):   # plans D batches ahead, D side streams in rotation: D plans in flight
+        D = 2 if mode == "depth2x2" else 3
+        sd = sides[b % D]
+        if ev_end[(b - 1) % nb] is not None:
+            sd.wait_event(ev_end[(b - 1) % nb])
+        with torch.cuda.stream(sd):
+            K.bpr_plan(args.users, args.items, args.k, *batches[(b + D) % nb], wss[(b + D) % nb])
+            e = torch.cuda.Event()
+            e.record(sd)
+            ev_plan[(b + D) % nb] = e
         if ev_plan[b] is not None:
             cur.wait_event(ev_plan[b])
         K.bpr_step(P, Q, sP, sQ, u, i, j, opt, wss[b], planned=True)
