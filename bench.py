@@ -318,6 +318,8 @@ def sharded_eval(args, K, sh, Pt, Qt, world, rank, device, barrier):
 ROCPROF_NAMES = {   # live name -> kernel name in `rocprofv3 --kernel-trace --stats` output (k=128: V=4, 32 lanes/row)
     "bpr_forward_kernel": "dr::bpr_forward_kernel<4, 32>",
     "bpr_forward_update_kernel": "dr::bpr_forward_update_1col_kernel<4, 32, 1>",
+    "bpr_tail_kernel": "dr::bpr_tail_kernel<4, 32, 1>",
+    "bpr_tail_combine_kernel": "dr::bpr_tail_combine_kernel<4, 32, 1>",
     "seg_update_kernel<item side>": "dr::seg_update_kernel<4, 32, 2, 1>",
     "seg_update_kernel<user side>": "dr::seg_update_kernel<4, 32, 1, 1>",
     "seg_long_partial_kernel": "dr::seg_long_partial_kernel<4, 32>",
@@ -374,7 +376,8 @@ def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step,
     out = {}
     # --- the kernels of the step, timed inside the running (pipelined, eager) step -------------------
     nb = len(batches)
-    prof = live_kernel_profile(K, lambda t: eager_step(t % nb), 4 * nb)
+    PROF_STEPS = 32 * nb                  # 256 launches of every kernel of the step
+    prof = live_kernel_profile(K, lambda t: eager_step(t % nb), PROF_STEPS)
     cQ = [segment_census(torch.cat((bi, bj))) for _, bi, bj in batches]
     cP = [segment_census(bu) for bu, _, _ in batches]
     mean = lambda xs: sum(xs) / len(xs)
@@ -383,34 +386,49 @@ def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step,
     upd = lambda c, short: (mean([x[0 if short else 2] for x in c]) * (rows_rw * row + 8)
                             + mean([x[1 if short else 3] for x in c]) * (row + 12))
     solo_rows = mean([x[5] for x in cQ]) + mean([x[5] for x in cP])
+    long_part = lambda c: mean([x[3] for x in c]) * (row + 12) + mean([x[4] for x in c]) * row
+    long_comb = lambda c: mean([x[4] for x in c]) * row + mean([x[2] for x in c]) * (rows_rw * row + 8)
     alg = {
         "bpr_forward_kernel": B * (12 + 3 * row + row + 16),            # ids, 3 rows; stash row, g, loss, 2 coefficients
-        # fused forward: the same, + 3 flags per sample, + for every single-contribution row its optimizer slots
-        # read and (w, slots) written (the row itself is already counted as read)
-        "bpr_forward_update_kernel": B * (12 + 3 + 3 * row + row + 16) + solo_rows * (rows_rw - 1) * row,
+        # fused forward, SURVEY 8(d) credit only: ids, every looked-up row read once, and for every single-contribution
+        # row its (w, m, v) read + written (the first read of w is the lookup already counted).  The stash rows, g /
+        # loss / coefficient writes and the solo flags are overhead, not credited.
+        "bpr_forward_update_kernel": B * 12 + 3 * B * row + solo_rows * (rows_rw - 1) * row,
         "seg_update_kernel<item side>": upd(cQ, True),
         "seg_update_kernel<user side>": upd(cP, True),
         # long segments: pass 1 reads the contributions and writes one partial row per 32; pass 2 reads the partial
         # rows and reads + writes (w, m, v)
-        "seg_long_partial_kernel": mean([x[3] for x in cQ]) * (row + 12) + mean([x[4] for x in cQ]) * row,
-        "seg_long_combine_kernel": mean([x[4] for x in cQ]) * row + mean([x[2] for x in cQ]) * (rows_rw * row + 8),
+        "seg_long_partial_kernel": long_part(cQ),
+        "seg_long_combine_kernel": long_comb(cQ),
+        # the fused step's tail: rows with 2 .. 4 contributions and the long segments' block partials, both tables
+        "bpr_tail_kernel": upd(cQ, True) + upd(cP, True) + long_part(cQ) + long_part(cP),
+        "bpr_tail_combine_kernel": long_comb(cQ) + long_comb(cP),
     }
-    traffic = {}
-    tp_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tp_path):           # HBM-side bytes per launch from rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        with open(tp_path) as f:
-            traffic = json.load(f).get("kernels", {})
+    # HBM-side bytes per launch: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, one pass each, corrected as
+    # MI355X_MICROARCH.md prescribes) over tools/step_loop.py -- the same kernels on the same batches, collected in a
+    # SEPARATE profiler run and committed under profiles/; not measured by this process
+    traffic, traffic_src = {}, None
+    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tp_path = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(tp_path):
+            with open(tp_path) as f:
+                traffic = json.load(f).get("kernels", {})
+            traffic_src = "profiles/" + cand
+            break
     kern = {}
     for nm, ts in prof.items():
         calls, t = len(ts), sum(ts) / len(ts)
-        e = {"avg_ms": t, "min_ms": min(ts), "max_ms": max(ts), "calls_per_step": calls / (4 * nb),
-             "rocprof_name": ROCPROF_NAMES.get(nm, nm)}
+        srt = sorted(ts)
+        e = {"avg_ms": t, "min_ms": srt[0], "median_ms": srt[len(srt) // 2], "max_ms": srt[-1], "launches": calls,
+             "calls_per_step": calls / PROF_STEPS, "rocprof_name": ROCPROF_NAMES.get(nm, nm)}
         if nm in alg and t > 0:
             e["algorithmic_bytes_per_launch"] = int(alg[nm])
             e["algorithmic_GBps"] = alg[nm] / (t * 1e-3) / 1e9
             e["frac_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBPS
+            e["frac_hbm_peak_min_median_max"] = [alg[nm] / (x * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                                                 for x in (srt[-1], srt[len(srt) // 2], srt[0])]
         if nm in traffic:
-            e["traffic_bytes_per_launch"] = traffic[nm]
+            e["traffic_bytes_per_launch_from_profiles"] = traffic[nm]
         kern[nm] = e
     out["kernels"] = kern
     # dominant kernel = the one that moves the most bytes per step (the long-segment passes run beside it on a
@@ -419,8 +437,13 @@ def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step,
     d = kern[name]
     out["roofline"] = {"bound": "hbm", "kernel": d["rocprof_name"], "achieved": d["algorithmic_GBps"],
                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["frac_hbm_peak"],
-                       "traffic": (traffic.get(name) or {}).get("hbm_bytes"), "avg_ms": d["avg_ms"],
+                       "frac_min_median_max": d["frac_hbm_peak_min_median_max"], "launches": d["launches"],
+                       "traffic": (traffic.get(name) or {}).get("hbm_bytes"),
+                       "traffic_source": (traffic_src + " (separate rocprofv3 --pmc passes, not this run)") if traffic_src else None,
+                       "avg_ms": d["avg_ms"], "median_ms": d["median_ms"],
                        "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                       "algorithmic_bytes": "SURVEY 8(d): 12 B ids + 3 looked-up rows per sample + (w, m, v) read and written "
+                                            "for every single-contribution row; stash / g / loss writes not credited",
                        "timing": "start/stop HIP events attached to each launch on its own stream (hipExtLaunchKernelGGL"
                                  " via dr_profile_enable), inside the pipelined eager step"}
     # standalone plan cost (generic API; the step itself uses one combined 3B-key plan built one batch ahead)
@@ -521,9 +544,17 @@ def cpu_baseline(args):
         t_total += time.perf_counter() - t0
         steps += 1
     others = cpu_other_flavours(args, P, Q, cdf, rng)
-    return {"value": steps * B / t_total, "unit": "train samples/s", "cores": 1, "kind": "port", "other_flavours": others,
-            "sample": "%d steps of B=%d on %dM users x %dM items d=%d (user table scaled to %d rows), %s touched-rows L2, "
-                      "scalar C port oracle/c/oracle.c:or_bpr_step" % (steps, B, args.users // 10**6, args.items // 10**6, k, Uc, args.opt),
+    scalar = {"value": steps * B / t_total, "unit": "train samples/s", "cores": 1,
+              "sample": "%d steps of B=%d, scalar C port oracle/c/oracle.c:or_bpr_step, ids resident" % (steps, B)}
+    ref = others.pop("torch_cpu_reference_shaped")
+    others["scalar_c_port"] = scalar
+    # headline = the flavour shaped like the reference's own control flow: per-positive Python negative
+    # draw and per-batch host feed (bprmf.py:126-150) around fp32 tensor math on the host cores (torch-CPU standing in
+    # for TensorFlow, which is not installable here).  The vectorised and the scalar-C figures sit beside it.
+    return {"value": ref["value"], "unit": "train samples/s", "cores": ref["cores"], "kind": "port",
+            "other_flavours": others,
+            "sample": ref["sample"] + "; %dM users x %dM items d=%d with the user table scaled to %d rows, %s touched-rows L2"
+                      % (args.users // 10**6, args.items // 10**6, k, Uc, args.opt),
             "host_cpus": os.cpu_count()}
 
 

@@ -29,10 +29,24 @@ struct PlanLayout {
 // partials in block order and applies the update -- the same blocked position order, in parallel.
 constexpr int LONG_SEG = 4;
 
-// rocPRIM's default configuration: below 1 M items a block sort + merge passes (9 launches for the 196 608 keys of
-// a C4 batch).  Forcing Onesweep (merge-sort limit 0) was measured and is slower here: plan 116 us instead of 75 us,
+// rocPRIM below 1 M items: a block sort + merge passes (9 launches for the 196 608 keys of a C4 batch with the default
+// configuration).  Forcing Onesweep (merge-sort limit 0) was measured and is slower here: plan 116 us instead of 75 us,
 // fused step 0.270 ms instead of 0.228 ms.
+// The merge-sort path with 4096 keys per block sort (1024 threads x 4): 48 sorted runs and 6 merge passes for the 196 608
+// keys of a C4 batch instead of 192 runs and 8 passes -- the plan is a chain of short dependent launches, so fewer
+// passes is what counts.  Measured, plan alone / pipelined step: default 91.1 / 177.3 us, 4 per thread 88.3 / 175.5,
+// 8 per thread (5 passes, but a slower block sort) 96.9 / 175.2.  Forcing Onesweep was measured in round 1: slower.
+// (DR_PLAN_SORT_IPT chooses the items per thread at build time; 0 = rocPRIM's default configuration.)
+#ifndef DR_PLAN_SORT_IPT
+#define DR_PLAN_SORT_IPT 4
+#endif
+#if DR_PLAN_SORT_IPT == 0
 using PlanSortConfig = rocprim::default_config;
+#else
+using PlanSortConfig = rocprim::radix_sort_config<rocprim::default_config,
+                                                  rocprim::merge_sort_config<512, 1024, DR_PLAN_SORT_IPT, 128, 128, 4>,
+                                                  rocprim::default_config, 1024 * 1024>;
+#endif
 
 static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
     size_t t_sort = 0, t_scan = 0;
@@ -208,30 +222,59 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
                                                         int32_t* __restrict__ long_seg, int32_t* __restrict__ long_cb,
                                                         int32_t* __restrict__ part_owner, int32_t* __restrict__ multi,
                                                         int32_t* __restrict__ long_cnt, int64_t n) {
+    // The three counters live in one cache line and device-scope atomics on one line are served one at a time by the
+    // memory side of this multi-XCD part (~8 ns each: 20 k per-row atomics made this kernel 22 us).  So: ONE atomic per
+    // workgroup and pass for the (many) rows with 2 .. LONG_SEG contributions, one per wavefront for the (few) long rows.
+    __shared__ int wcnt[4], wbase[4];
     const int nseg = hdr[0];
-    const int lane = threadIdx.x & 63;
-    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * 256) {
-        const int len = seg_start[s + 1] - seg_start[s];
-        if (len > LONG_SEG) {
-            const int l = atomicAdd(&hdr[1], 1);
-            const int nch = (len + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK;
-            const int cb = atomicAdd(&hdr[2], nch);
-            long_seg[l] = (int32_t)s;
-            long_cb[l] = cb;
-            long_cnt[l] = 0;
-            for (int c = 0; c < nch; ++c) part_owner[cb + c] = l;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t s0 = (int64_t)blockIdx.x * 256; s0 < nseg; s0 += stride) {   // block-uniform trip count
+        const int64_t s = s0 + threadIdx.x;
+        const int len = s < nseg ? seg_start[s + 1] - seg_start[s] : 0;
+        // long rows: count and block total of this wavefront, one atomic each
+        const bool is_long = len > LONG_SEG;
+        const unsigned long long ml = __ballot(is_long);
+        if (ml) {
+            const int nch = is_long ? (len + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK : 0;
+            int incl = nch;                                   // inclusive prefix sum of nch over the wavefront
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            const int total = __shfl(incl, 63, 64);
+            int l0 = 0, c0 = 0;
+            if (lane == 0) {
+                l0 = atomicAdd(&hdr[1], __popcll(ml));
+                c0 = atomicAdd(&hdr[2], total);
+            }
+            l0 = __shfl(l0, 0, 64);
+            c0 = __shfl(c0, 0, 64);
+            if (is_long) {
+                const int l = l0 + __popcll(ml & ((1ull << lane) - 1ull));
+                const int cb = c0 + incl - nch;
+                long_seg[l] = (int32_t)s;
+                long_cb[l] = cb;
+                long_cnt[l] = 0;
+                for (int c = 0; c < nch; ++c) part_owner[cb + c] = l;
+            }
         }
-        // one atomic per wavefront for the (many) rows with 2 .. LONG_SEG contributions: 20 k same-address atomics
-        // made this kernel 22 us instead of 9
         const bool is_multi = len >= 2 && len <= LONG_SEG;
         const unsigned long long m = __ballot(is_multi);
-        if (is_multi) {
-            const int leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&hdr[4], __popcll(m));
-            base = __shfl(base, leader, 64);
-            multi[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            int base = t ? atomicAdd(&hdr[4], t) : 0;
+            for (int w = 0; w < 4; ++w) {
+                wbase[w] = base;
+                base += wcnt[w];
+            }
         }
+        __syncthreads();
+        if (is_multi) multi[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
+        __syncthreads();
     }
 }
 

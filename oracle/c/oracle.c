@@ -29,6 +29,13 @@ void or_init_normal(float* w, int64_t count, uint64_t seed, float stddev) {
     for (int64_t i = 0; i < count; ++i) w[i] = stddev * or_counter_normal(seed, (uint64_t)i);
 }
 
+/* rows of a counter-initialised table without building the table: w[r, c] = stddev * normal(seed, rows[r] * k + c)
+ * (what dr_init_normal_f32 writes at element rows[r] * k + c) -- full-size C4 tests check sampled rows this way */
+void or_init_rows(float* w, const int64_t* rows, int64_t n, int k, uint64_t seed, float stddev) {
+    for (int64_t r = 0; r < n; ++r)
+        for (int c = 0; c < k; ++c) w[r * k + c] = stddev * or_counter_normal(seed, (uint64_t)rows[r] * (uint64_t)k + (uint64_t)c);
+}
+
 static float chain_dot(const float* a, const float* b, int k) {
     float acc = 0.0f;
     for (int c = 0; c < k; ++c) acc = fmaf(a[c], b[c], acc);

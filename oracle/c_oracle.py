@@ -44,6 +44,14 @@ def init_normal(count, seed, stddev):
     return w
 
 
+def init_rows(rows, k, seed, stddev):
+    """Rows `rows` of a [*, k] table initialised by dr_init_normal_f32(seed, stddev) (no table is built)."""
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    w = np.empty((len(rows), k), np.float32)
+    lib().or_init_rows(_p(w), _p(rows), C.c_int64(len(rows)), C.c_int(k), C.c_uint64(seed), C.c_float(stddev))
+    return w
+
+
 def sample_negatives(train_ptr, train_idx, users, num_item, seed, offset=0, n_neg=1, first_item=0):
     """or_sample_negatives: uniform draws from all items minus the user's train items (bprmf.py:126-133,175-181)."""
     train_ptr, train_idx, users = _i32(train_ptr), _i32(train_idx), _i32(users)

@@ -934,3 +934,81 @@ def test_caser_hconv_empty_batch_and_limits(dev):
     big = torch.zeros((1, 65, 4), device=dev)
     with pytest.raises(DeepRecError):
         K.caser_hconv_forward(big, torch.zeros((K.hconv_rows(1, 66), 4), device=dev), torch.zeros(65, device=dev), 1)
+
+
+def test_c4_full_size_step_planned_equals_unplanned_and_oracle_rows(dev):
+    """BASELINE config 4 at FULL size on one GPU (10 M users x 1 M items, d = 128, B = 65 536, Adam, touched-rows L2):
+    (a) the planned + fused step (what bench.py times) == the unplanned dr_bpr_step_f32, every table and slot bit for
+    bit; (b) a second planned run on fresh tables gives the same bits (no race, no launch-order dependence);
+    (c) 64 sampled rows -- solo user rows, solo item rows and the 16 hottest items (segments of thousands of
+    contributions) -- against the oracle row update computed from counter-initialised rows, bit for bit, with the
+    device's forward coefficients g fed to the oracle (transcendentals checked separately to 1e-6)."""
+    from deeprec_amd import kernels as K
+    nu, ni, k, B = 10_000_000, 1_000_000, 128, 65536
+    rng = np.random.default_rng(44)
+    u = rng.integers(0, nu, B).astype(np.int32)
+    u[1000:1016] = u[0]                                       # a user shared by 17 samples: a long user-side segment
+    w = np.arange(1, ni + 1, dtype=np.float64) ** -1.05
+    cdf = np.cumsum(w) / w.sum()
+    i = np.minimum(np.searchsorted(cdf, rng.random(B)), ni - 1).astype(np.int32)
+    j = rng.integers(0, ni, B).astype(np.int32)
+    ud, idd, jd = T(u, dev), T(i, dev), T(j, dev)
+    hp = dict(alpha=float(ro.adam_alpha(1e-3, 0.9, 0.999, 1)), beta1=0.9, beta2=0.999, eps=1e-7)
+    opt = K.opt_params(K.OPT_ADAM, alpha=hp["alpha"], eps=1e-7, reg=0.1, reg_mode=K.REG_TOUCHED)
+
+    def fresh():
+        P = torch.empty((nu, k), dtype=torch.float32, device=dev)
+        Q = torch.empty((ni, k), dtype=torch.float32, device=dev)
+        K.init_normal_(P, 1, 0.01)
+        K.init_normal_(Q, 2, 0.01)
+        return P, Q, [torch.zeros_like(P), torch.zeros_like(P)], [torch.zeros_like(Q), torch.zeros_like(Q)]
+    P0, Q0, sP0, sQ0 = fresh()
+    g_dev = N(K.bpr_forward(P0, Q0, ud, idd, jd)[0])
+    la = float(K.bpr_step(P0, Q0, sP0, sQ0, ud, idd, jd, opt).item())               # unplanned
+    results = []
+    for _ in range(2):
+        P1, Q1, sP1, sQ1 = fresh()
+        ws = K.StepWorkspace(B, k, nu, ni, K.REG_TOUCHED, dev)
+        K.bpr_plan(nu, ni, k, ud, idd, jd, ws)
+        lb = float(K.bpr_step(P1, Q1, sP1, sQ1, ud, idd, jd, opt, ws, planned=True).item())
+        assert lb == la
+        if not results:
+            for a, b in ((P0, P1), (Q0, Q1), (sP0[0], sP1[0]), (sP0[1], sP1[1]), (sQ0[0], sQ1[0]), (sQ0[1], sQ1[1])):
+                assert torch.equal(a, b)
+            del P0, sP0                                        # 15 GB back before the second planned run
+            results.append((P1, Q1, sP1, sQ1))
+        else:
+            for a, b in zip((P1, Q1) + tuple(sP1) + tuple(sQ1), (results[0][0], results[0][1]) + tuple(results[0][2]) + tuple(results[0][3])):
+                assert torch.equal(a, b)
+    P1, Q1, sP1, sQ1 = results[0]
+    # ---- (c) sampled rows against the oracle ----------------------------------------------------------------------
+    # forward coefficients: device vs numpy to 1e-6, then the device's are used so that everything after is exact
+    pu, qi, qj = co.init_rows(u[:512], k, 1, 0.01), co.init_rows(i[:512], k, 2, 0.01), co.init_rows(j[:512], k, 2, 0.01)
+    x = (pu * qi).sum(1) - (pu * qj).sum(1)
+    np.testing.assert_allclose(g_dev[:512], -(1 - 1 / (1 + np.exp(-x.astype(np.float64)))), rtol=1e-5, atol=1e-7)
+    cnt_u = np.bincount(u, minlength=0)
+    users = [int(u[0])] + [int(x_) for x_ in u[2000:2031]]
+    cnt_i = np.bincount(np.concatenate((i, j)), minlength=ni)
+    solo_items = [int(x_) for x_ in j if cnt_i[x_] == 1][:16]
+    hot_items = list(range(16))
+    assert cnt_i[0] > 1000 and (cnt_u[u[0]] >= 17) and len(solo_items) == 16
+    for uu in users:
+        bs = np.flatnonzero(u == uu)
+        d = co.init_rows(i[bs], k, 2, 0.01) - co.init_rows(j[bs], k, 2, 0.01)
+        src = (g_dev[bs][:, None] * d).astype(np.float32)
+        W, sl = ro.sparse_row_update(ro.OPT_ADAM, co.init_rows([uu], k, 1, 0.01), [np.zeros((1, k), np.float32)] * 2,
+                                     np.zeros(len(bs), np.int64), src, None, None, 0.1, ro.REG_TOUCHED, hp)
+        assert np.array_equal(N(P1[uu]), W[0]) and np.array_equal(N(sP1[0][uu]), sl[0][0]) and \
+            np.array_equal(N(sP1[1][uu]), sl[1][0]), "user row %d" % uu
+    ids2 = np.concatenate((i, j))
+    coef2 = np.concatenate((g_dev, -g_dev)).astype(np.float32)
+    for it in solo_items + hot_items:
+        es = np.flatnonzero(ids2 == it)                        # position order in the list [i ; j]
+        src = co.init_rows(u[es % B], k, 1, 0.01)
+        W, sl = ro.sparse_row_update(ro.OPT_ADAM, co.init_rows([it], k, 2, 0.01), [np.zeros((1, k), np.float32)] * 2,
+                                     np.zeros(len(es), np.int64), src, None, coef2[es], 0.1, ro.REG_TOUCHED, hp)
+        assert np.array_equal(N(Q1[it]), W[0]) and np.array_equal(N(sQ1[0][it]), sl[0][0]) and \
+            np.array_equal(N(sQ1[1][it]), sl[1][0]), "item row %d (%d contributions)" % (it, len(es))
+    # rows no sample touches keep their initial bits
+    quiet = np.setdiff1d(np.arange(ni - 5000, ni), ids2)[:8]
+    assert np.array_equal(N(Q1[T(quiet, dev).long()]), co.init_rows(quiet, k, 2, 0.01))

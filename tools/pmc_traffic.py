@@ -1,5 +1,5 @@
 """Summarise rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, one pass each) of tools/step_loop.py into
-profiles/r01_pmc_traffic.json: mean HBM-side bytes per launch for each library kernel.
+profiles/r02_pmc_traffic.json (or the name given as third argument): mean HBM-side bytes per launch for each library kernel.
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $REPO/gpurun_out/pmc_fetch -o f --output-format csv -- python $REPO/tools/step_loop.py
@@ -22,6 +22,8 @@ SHORT = {
     "seg_update_kernel<4, 32, 1, 1>": "seg_update_kernel<user side>",
     "seg_long_partial_kernel": "seg_long_partial_kernel",
     "seg_long_combine_kernel": "seg_long_combine_kernel",
+    "bpr_tail_kernel": "bpr_tail_kernel",
+    "bpr_tail_combine_kernel": "bpr_tail_combine_kernel",
 }
 
 
@@ -54,7 +56,8 @@ def main():
         out["kernels"][k] = {"fetch_bytes": fb, "write_bytes": wb,
                              "hbm_bytes": (fb or 0) + (wb or 0) if (fb is not None and wb is not None) else None,
                              "launches": [len(fs), len(wsz)]}
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
+    name = sys.argv[3] if len(sys.argv) > 3 else "r02_pmc_traffic.json"
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))
