@@ -68,6 +68,7 @@ SIGNATURES = {
     "dr_adam_tick_f32": (_i32, [_p, _f, _f, _f, _p]),
     "dr_sum_f32": (_i32, [_p, _i64, _p, _p]),
     "dr_sample_negatives_i32": (_i32, [_p, _p, _p, _i64, _i32, _i64, _i64, _i64, C.c_uint64, C.c_uint64, _p, _p]),
+    "dr_sample_negatives_excl_i32": (_i32, [_p, _i64, _i32, _i32, _i64, _i64, C.c_uint64, C.c_uint64, _p, _p]),
     "dr_bucket_order_bytes": (_i64, [_i64]),
     "dr_bucket_order_i32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "dr_route_bytes": (_i64, [_i64]),

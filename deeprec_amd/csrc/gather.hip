@@ -224,7 +224,62 @@ __global__ __launch_bounds__(256) void sample_neg_kernel(const int32_t* __restri
         out[x] = res;
     }
 }
+
+// The sequence models' sampler (AttRec.py:448-466, _get_neg_items_sbpr): the pool of sample e is every item
+// first_item .. num_item-1 EXCEPT the sample's own T targets; out[e*n_neg + d] = pool[s], s = floor(r * |pool| / 2^32).
+// T is small (the reference uses 3): the distinct in-range targets are insertion-sorted in registers and the s-th
+// item of the complement is found by walking them (target[p] - p <= s), like the host code in _seq_common.py.
+constexpr int EXCL_MAX_T = 16;
+__global__ __launch_bounds__(256) void sample_neg_excl_kernel(const int32_t* __restrict__ targets, int64_t n, int T,
+                                                              int n_neg, int64_t num_item, int64_t first_item,
+                                                              uint64_t seed, uint64_t offset, int32_t* __restrict__ out) {
+    const int64_t total = n * n_neg;
+    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < total; x += (int64_t)gridDim.x * 256) {
+        const int64_t e = x / n_neg;
+        int64_t t[EXCL_MAX_T];
+        int m = 0;
+        for (int q = 0; q < T; ++q) {
+            const int64_t v = targets[e * T + q];
+            if (v < first_item || v >= num_item) continue;
+            int p = m;
+            bool dup = false;
+            while (p > 0 && t[p - 1] >= v) {
+                if (t[p - 1] == v) { dup = true; break; }
+                --p;
+            }
+            if (dup) continue;
+            for (int z = m; z > p; --z) t[z] = t[z - 1];
+            t[p] = v;
+            ++m;
+        }
+        const int64_t cnt = (num_item - first_item) - m;
+        int32_t res = -1;
+        if (cnt > 0) {
+            const uint64_t r = counter_u32(seed, offset + (uint64_t)x);
+            const int64_t sidx = (int64_t)((r * (uint64_t)cnt) >> 32);
+            int lo = 0;
+            while (lo < m && t[lo] - first_item - lo <= sidx) ++lo;
+            res = (int32_t)(sidx + lo + first_item);
+        }
+        out[x] = res;
+    }
+}
 }  // namespace dr
+
+extern "C" int32_t dr_sample_negatives_excl_i32(const int32_t* targets, int64_t n, int32_t T, int32_t n_neg,
+                                                int64_t num_item, int64_t first_item, uint64_t seed, uint64_t offset,
+                                                int32_t* out, void* stream) {
+    DR_REQUIRE(n >= 0 && n_neg >= 1 && T >= 0 && T <= dr::EXCL_MAX_T && num_item >= 0 && first_item >= 0 &&
+                   first_item <= num_item,
+               "dr_sample_negatives_excl_i32: bad sizes (T <= %d)", dr::EXCL_MAX_T);
+    DR_REQUIRE(num_item < (1ll << 31), "dr_sample_negatives_excl_i32: num_item too large for int32 item ids");
+    if (n == 0) return DR_OK;
+    DR_REQUIRE(out && (targets || T == 0), "dr_sample_negatives_excl_i32: NULL pointer");
+    DR_LAUNCH(dr::sample_neg_excl_kernel, dim3(dr::grid_for(n * n_neg, 256)), dim3(256), 0, (hipStream_t)stream, targets,
+              n, (int)T, (int)n_neg, num_item, first_item, seed, offset, out);
+    DR_CHECK_LAUNCH("dr_sample_negatives_excl_i32");
+    return DR_OK;
+}
 
 extern "C" int32_t dr_sample_negatives_i32(const int32_t* train_ptr, const int32_t* train_idx, const int32_t* users,
                                            int64_t n, int32_t n_neg, int64_t num_user, int64_t num_item,

@@ -162,6 +162,18 @@ def sample_negatives(train_ptr, train_idx, users, num_item, seed, offset=0, n_ne
     return out
 
 
+def sample_negatives_excl(targets, num_item, seed, offset=0, n_neg=1, first_item=1):
+    """n_neg uniform draws per row of `targets` (int32 [n, T]) from the items first_item .. num_item-1 that are not
+    among the row's own targets (AttRec.py:448-466).  int32 [n, n_neg]."""
+    targets = _req(targets, torch.int32, "targets", 2)
+    n, T = targets.shape
+    out = torch.empty((n, n_neg), dtype=torch.int32, device=targets.device)
+    check(_abi.lib().dr_sample_negatives_excl_i32(_ptr(targets), n, T, int(n_neg), int(num_item), int(first_item),
+                                                  int(seed), int(offset), _ptr(out), _stream()),
+          "dr_sample_negatives_excl_i32")
+    return out
+
+
 def bucket_order(keys, nkeys):
     """Stable bucketing of small integer keys in [0, nkeys) (routing by owner rank, deeprec_amd/sharding.py):
     returns (order int32 [n]: positions in ascending key order, ties in input order; counts int64 [nkeys]).

@@ -21,8 +21,14 @@ class CML(object):
     _name = "CML"
 
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.1, reg_rate=0.1, epoch=500, batch_size=500,
-                 verbose=False, t=5, display_step=1000, device=None):
+                 verbose=False, t=5, display_step=1000, device=None, sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device'")
+        # "reference": the per-positive np.random draw of cml.py:108-111 (same RNG stream); "device": the same
+        # distribution from dr_sample_negatives_i32 over the train CSR, no Python loop
+        self.sampler = sampler
+        self._train_csr_dev = None
         self.learning_rate = learning_rate
         self.reg_rate = reg_rate
         self.epochs = epoch
@@ -84,10 +90,17 @@ class CML(object):
         idxs = np.random.permutation(self.num_training)  # shuffled ordering
         user_random = self.user[idxs]
         item_random = self.item[idxs]
-        item_random_neg = sample_uniform_negatives(user_random, self.neg_items)[:, 0]
         u_d = to_dev(user_random, torch.int32, self.device)
         i_d = to_dev(item_random, torch.int32, self.device)
-        j_d = to_dev(item_random_neg, torch.int32, self.device)
+        if self.sampler == "device":
+            if self._train_csr_dev is None:
+                c = self.neg_items.csr
+                self._train_csr_dev = (to_dev(c.indptr, torch.int32, self.device), to_dev(c.indices, torch.int32, self.device))
+            seed = int(np.random.randint(0, 2 ** 31 - 1))       # one draw per epoch keeps np.random.seed() reproducible
+            j_d = K.sample_negatives(*self._train_csr_dev, u_d, self.num_item, seed)[:, 0].contiguous()
+        else:
+            item_random_neg = sample_uniform_negatives(user_random, self.neg_items)[:, 0]
+            j_d = to_dev(item_random_neg, torch.int32, self.device)
         for i in range(self.total_batch):
             start_time = time.time()
             s = slice(i * self.batch_size, (i + 1) * self.batch_size)

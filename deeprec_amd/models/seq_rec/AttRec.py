@@ -32,7 +32,7 @@ def timing_signal(length, channels, device, min_timescale=1.0, max_timescale=1.0
 
 class AttRec(SeqBase):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.05, reg_rate=1e-2, epoch=5000, batch_size=1000,
-                 show_time=False, T=1, display_step=1000, verbose=False, device=None, shard=None):
+                 show_time=False, T=1, display_step=1000, verbose=False, device=None, shard=None, sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
         self.shard = shard if (shard is not None and shard.world > 1) else None    # _common.Shard: DP over ranks
         self.learning_rate = learning_rate
@@ -45,6 +45,9 @@ class AttRec(SeqBase):
         self.display_step = display_step
         self.device = device_of(device)
         self.neg_items = dict()
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device'")
+        self.sampler = sampler
         self.alpha = 0.2
         print("AttSeqRec.")
 

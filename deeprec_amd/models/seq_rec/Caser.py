@@ -69,7 +69,7 @@ def caser_convs_fused(e, conv_v_w, conv_v_b, hw_cat, hb_cat, n_h):
 
 class Caser(SeqBase):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.001, reg_rate=1e-6, epoch=500, batch_size=1000,
-                 show_time=False, T=1, display_step=1000, verbose=False, device=None, shard=None):
+                 show_time=False, T=1, display_step=1000, verbose=False, device=None, shard=None, sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
         self.shard = shard if (shard is not None and shard.world > 1) else None    # _common.Shard: DP over ranks
         self.learning_rate = learning_rate
@@ -82,9 +82,22 @@ class Caser(SeqBase):
         self.display_step = display_step
         self.device = device_of(device)
         self.neg_items = dict()
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device'")
+        self.sampler = sampler
         print("Caser.")
 
-    def build_network(self, L, num_T, n_h=16, n_v=4, num_factor=150, num_neg=2, init=None, lazy_v=True):
+    def build_network(self, L, num_T, n_h=16, n_v=4, num_factor=150, num_neg=2, init=None, lazy_v=True,
+                      neg_alignment="intended"):
+        """neg_alignment: Caser.train draws its negatives with _get_neg_items(self.users.squeeze(), ...) (Caser.py:243) --
+        row r of the negatives is drawn from the pool of the r-th user in STORAGE order, but is fed next to the r-th user
+        of the PERMUTED epoch (Caser.py:237-254), so a sample trains against negatives of an unrelated user (which may
+        be its own user's positives).  "intended" (default) draws row r for the user it is fed with; "reference"
+        reproduces the reference's misalignment draw for draw.  Either way the pool is the
+        user's whole-train-row complement neg_items[u] (Caser.py:302-319), not the targets-only pool of AttRec / PRME."""
+        if neg_alignment not in ("intended", "reference"):
+            raise ValueError("neg_alignment must be 'intended' or 'reference'")
+        self.neg_alignment = neg_alignment
         self.n_h, self.n_v, self.L, self.num_T, self.num_factor, self.num_neg = n_h, n_v, L, num_T, num_factor, num_neg
         dev, d = self.device, num_factor
         init = init or {}
@@ -164,6 +177,18 @@ class Caser(SeqBase):
 
     def prepare_data(self, train_data, test_data):
         self._prepare(train_data, test_data)
+
+    def _epoch_negatives(self, usr_r, tar_r, n_neg):
+        """Caser.py:243,302-319: pool = neg_items[u] (see build_network: neg_alignment)."""
+        users = self.users[:, 0] if self.neg_alignment == "reference" else usr_r
+        return self._sample_negatives_users(users, n_neg)
+
+    def _epoch_negatives_device(self, u_d, t_d, n_neg, seed):
+        if getattr(self, "_train_csr_dev", None) is None:
+            c = self.neg_items.csr
+            self._train_csr_dev = (to_dev(c.indptr, torch.int32, self.device), to_dev(c.indices, torch.int32, self.device))
+        users = to_dev(self.users[:, 0], torch.int32, self.device) if self.neg_alignment == "reference" else u_d
+        return K.sample_negatives(*self._train_csr_dev, users, self.num_item, seed, n_neg=n_neg, first_item=1)
 
     def train(self, train_data):
         self.test_sequences = train_data.test_sequences.sequences

@@ -16,7 +16,7 @@ from ._seq_common import SeqBase
 
 class PRME(SeqBase):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.001, reg_rate=1e-2, epoch=5000, batch_size=1000,
-                 show_time=False, T=1, display_step=1000, verbose=False, device=None):
+                 show_time=False, T=1, display_step=1000, verbose=False, device=None, sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
         self.learning_rate = learning_rate
         self.epochs = epoch
@@ -28,6 +28,9 @@ class PRME(SeqBase):
         self.display_step = display_step
         self.device = device_of(device)
         self.neg_items = dict()
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' or 'device'")
+        self.sampler = sampler
         self.alpha = 0.2
         print("PRME.")
 

@@ -42,18 +42,43 @@ class SeqBase:
                 out[r, j] = s + lo + 1
         return out
 
+    def _sample_negatives_users(self, users, n):
+        """Caser.py:302-319 (_get_neg_items): n draws per row from neg_items[u] = all items 1..num_item-1 minus the
+        user's whole train row, one np.random.randint(len(pool)) per draw -- same RNG stream, pools addressed through
+        the train CSR without being built."""
+        out = np.zeros((len(users), n))
+        for r, u in enumerate(users):
+            c = self.neg_items.count(int(u))
+            for j in range(n):
+                out[r, j] = self.neg_items.nth(int(u), np.random.randint(c))
+        return out
+
+    def _epoch_negatives(self, usr_r, tar_r, n_neg):
+        """Host sampling of one epoch (AttRec / PRME: pool = all items minus the sample's own targets)."""
+        return self._sample_negatives(tar_r, n_neg)
+
+    def _epoch_negatives_device(self, u_d, t_d, n_neg, seed):
+        """The same pools sampled on the device: dr_sample_negatives_excl_i32."""
+        from ... import kernels as K
+        return K.sample_negatives_excl(t_d, self.num_item, seed, n_neg=n_neg, first_item=1)
+
     def _train_epoch(self, n_neg):
-        """AttRec.py:356-387 / Caser / PRME: permutation, per-sample negatives, batches (remainder dropped)."""
+        """AttRec.py:356-387 / Caser / PRME: permutation, per-sample negatives, batches (remainder dropped).
+        sampler = "reference" (default): the reference's nested Python loops, draw for draw; "device": the same
+        distribution from the HIP sampler, no per-sample host work."""
         self.num_training = len(self.sequences)
         self.total_batch = int(self.num_training / self.batch_size)
         idxs = np.random.permutation(self.num_training)
         seq_r, tar_r, usr_r = self.sequences[idxs], self.targets[idxs], self.users[idxs][:, 0]
-        neg_r = self._sample_negatives(tar_r, n_neg)
         dev = self.device
         u_d = to_dev(usr_r, torch.int32, dev)
         s_d = to_dev(seq_r, torch.int32, dev)
         t_d = to_dev(tar_r, torch.int32, dev)
-        n_d = to_dev(neg_r, torch.int32, dev)
+        if getattr(self, "sampler", "reference") == "device":
+            seed = int(np.random.randint(0, 2 ** 31 - 1))     # one host draw per epoch keeps np.random.seed() reproducible
+            n_d = self._epoch_negatives_device(u_d, t_d, n_neg, seed).contiguous()
+        else:
+            n_d = to_dev(self._epoch_negatives(usr_r, tar_r, n_neg), torch.int32, dev)
         step = getattr(self, "_step", None) or self.train_op
         for i in range(self.total_batch):
             start_time = time.time()

@@ -326,6 +326,13 @@ int32_t dr_sample_negatives_i32(const int32_t* train_ptr, const int32_t* train_i
                                 int32_t n_neg, int64_t num_user, int64_t num_item, int64_t first_item,
                                 uint64_t seed, uint64_t offset, int32_t* out, void* stream);
 
+/* The sequence models' sampler (AttRec.py:448-466 _get_neg_items_sbpr, used by AttRec.py:356-387 and PRME.py:133-160):
+ * the pool of sample e is every item first_item .. num_item-1 except the sample's own targets[e, 0..T) (T <= 16);
+ * out[e*n_neg + d] = pool[floor(r * |pool| / 2^32)] with the same counter-based r as above.  Same distribution as the
+ * reference's np.random.randint(len(pool)) per draw; the same numbers as oracle/c/oracle.c:or_sample_negatives_excl. */
+int32_t dr_sample_negatives_excl_i32(const int32_t* targets, int64_t n, int32_t T, int32_t n_neg, int64_t num_item,
+                                     int64_t first_item, uint64_t seed, uint64_t offset, int32_t* out, void* stream);
+
 /* ---- multi-GPU routing helper (no counterpart in the reference, which is single-device) ----
  * Stable bucketing of n small keys in [0, nkeys), nkeys <= 256 (key = owning rank of a looked-up row):
  * order[x] = position of the x-th element in ascending key order, ties in input order; counts[b] = number of

@@ -187,6 +187,31 @@ static uint32_t or_counter_u32(uint64_t seed, uint64_t idx) {
     return (uint32_t)(z >> 32);
 }
 
+/* AttRec.py:448-466 (_get_neg_items_sbpr): pool = all items first_item .. num_item-1 minus the sample's own targets,
+ * built as a list like the reference does; draw = pool[floor(r * |pool| / 2^32)] */
+void or_sample_negatives_excl(const int32_t* targets, int64_t n, int32_t T, int32_t n_neg, int64_t num_item,
+                              int64_t first_item, uint64_t seed, uint64_t offset, int32_t* out) {
+    int32_t* cand = (int32_t*)malloc(sizeof(int32_t) * (size_t)(num_item > 0 ? num_item : 1));
+    for (int64_t e = 0; e < n; ++e) {
+        int64_t cnt = 0;
+        for (int64_t it = first_item; it < num_item; ++it) {
+            int is_t = 0;
+            for (int q = 0; q < T; ++q) is_t |= (targets[e * T + q] == it);
+            if (!is_t) cand[cnt++] = (int32_t)it;
+        }
+        for (int d = 0; d < n_neg; ++d) {
+            const int64_t x = e * n_neg + d;
+            if (cnt <= 0) {
+                out[x] = -1;
+                continue;
+            }
+            const uint64_t r = or_counter_u32(seed, offset + (uint64_t)x);
+            out[x] = cand[(r * (uint64_t)cnt) >> 32];
+        }
+    }
+    free(cand);
+}
+
 void or_sample_negatives(const int32_t* train_ptr, const int32_t* train_idx, const int32_t* users, int64_t n,
                          int32_t n_neg, int64_t num_user, int64_t num_item, int64_t first_item, uint64_t seed,
                          uint64_t offset, int32_t* out) {

@@ -62,6 +62,16 @@ def sample_negatives(train_ptr, train_idx, users, num_item, seed, offset=0, n_ne
     return out
 
 
+def sample_negatives_excl(targets, num_item, seed, offset=0, n_neg=1, first_item=1):
+    """or_sample_negatives_excl: uniform draws from all items minus the row's own targets (AttRec.py:448-466)."""
+    targets = np.ascontiguousarray(targets, dtype=np.int32)
+    n, T = targets.shape
+    out = np.empty((n, n_neg), np.int32)
+    lib().or_sample_negatives_excl(_p(targets), C.c_int64(n), C.c_int32(T), C.c_int32(n_neg), C.c_int64(num_item),
+                                   C.c_int64(first_item), C.c_uint64(seed), C.c_uint64(offset), _p(out))
+    return out
+
+
 def pair_dot(A, B, ai, bi):
     A, B, ai, bi = _f32(A), _f32(B), _i32(ai), _i32(bi)
     out = np.empty(len(ai), np.float32)

@@ -712,3 +712,164 @@ def test_dense_l2_step_without_dense_gradient_is_exact(dev, kind):
     for x, y in zip(sa, sb):
         assert torch.equal(x, y)
     assert int(a.row_flags().sum()) == 0 and getattr(b, "_flags", None) is None
+
+
+# ---------------------------------------------------------------------------------------------------
+# host-side sampling / batching of the reference, replayed draw for draw
+# ---------------------------------------------------------------------------------------------------
+def _reference_pointwise_epoch(user, item, label, neg_items, n_neg, seed):
+    """gmf.py:100-124 / neumf.py:153-180 restated literally: random.sample per positive, label 0, one permutation."""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    item_temp, user_temp, labels_temp = item[:], user[:], label[:]
+    user_append, item_append, values_append = [], [], []
+    for u in user:
+        list_of_random_items = random.sample(neg_items[u], n_neg)
+        user_append += [u] * n_neg
+        item_append += list_of_random_items
+        values_append += [0] * n_neg
+    item_temp += item_append
+    user_temp += user_append
+    labels_temp += values_append
+    idxs = np.random.permutation(len(item_temp))
+    return np.array(user_temp)[idxs], np.array(item_temp)[idxs], np.array(labels_temp)[idxs]
+
+
+def test_pointwise_models_reference_sampling_stream(dev):
+    """GMF.train / NeuMF.train in the default (reference) sampler mode consume Python's `random` and numpy's RNG
+    exactly as gmf.py:100-124 and neumf.py:153-180 do: same negatives, same shuffle, same batches (remainder
+    dropped), for the same seeds."""
+    import random
+    from deeprec_amd.models.item_ranking.gmf import GMF
+    from deeprec_amd.models.item_ranking.neumf import NeuMF
+    rng = np.random.default_rng(21)
+    nu, ni, B = 30, 45, 64
+    train, test = _toy_data(rng, nu, ni, 9)
+    csr = train.tocsr()
+    neg = {u: sorted(set(range(ni)) - set(csr.getrow(u).nonzero()[1])) for u in range(nu)}
+    coo = train.tocoo()
+    user, item, label = list(coo.row.reshape(-1)), list(coo.col.reshape(-1)), list(coo.data)
+    for cls, n_neg in ((GMF, 5), (NeuMF, 7)):
+        m = quiet(cls, None, nu, ni, 0.5, 0.01, 1, B)
+        quiet(m.build_network, num_neg_sample=n_neg)
+        quiet(m.prepare_data, train, test)
+        ur, ir, yr = _reference_pointwise_epoch(user, item, label, neg, n_neg, 77)
+        got = []
+        if cls is GMF:
+            m.train_op = lambda u_, i_, y_: got.append((u_.cpu().numpy(), i_.cpu().numpy(), y_.cpu().numpy())) or torch.zeros(1)
+        else:
+            m._step = lambda u_, i_, y_: got.append((u_.cpu().numpy(), i_.cpu().numpy(), y_.cpu().numpy())) or torch.zeros(1)
+        random.seed(77)
+        np.random.seed(77)
+        quiet(m.train)
+        assert len(got) == len(ur) // B and len(got) > 3
+        for b, (gu, gi, gy) in enumerate(got):
+            s = slice(b * B, (b + 1) * B)
+            assert np.array_equal(gu, ur[s]) and np.array_equal(gi, ir[s]) and np.array_equal(gy, yr[s].astype(np.float32)), (cls.__name__, b)
+
+
+def test_nfm_train_shuffle_and_test_clipping_match_reference(dev):
+    """nfm.py:91-111: labels and feature rows are shuffled by the SAME permutation (RNG state replayed), batches are
+    consecutive slices, the remainder is dropped; nfm.py:113-131: test predictions are clipped to the label range
+    before the RMSE."""
+    import math
+    from deeprec_amd.models.rating_prediction.nfm import NFM
+    rng = np.random.default_rng(8)
+    M, Fd, n, B = 50, 4, 150, 32
+    X = rng.integers(0, M, (n, Fd)).tolist()
+    Y = [[float(v)] for v in rng.choice([-1.0, 1.0], n)]
+    m = quiet(NFM, None, 10, 10, 0.05, 0.01, 1, B)
+    quiet(m.build_network, M, 8, 8)
+    got = []
+    m._step = lambda x_, y_: got.append((x_.cpu().numpy(), y_.cpu().numpy())) or torch.zeros(1)
+    data = {"X": [r[:] for r in X], "Y": [r[:] for r in Y]}
+    np.random.seed(5)
+    quiet(m.train, data)
+    # the reference's lines on plain lists
+    ref = {"X": [r[:] for r in X], "Y": [r[:] for r in Y]}
+    np.random.seed(5)
+    rng_state = np.random.get_state()
+    np.random.shuffle(ref["Y"])
+    np.random.set_state(rng_state)
+    np.random.shuffle(ref["X"])
+    assert len(got) == n // B
+    for b, (gx, gy) in enumerate(got):
+        assert np.array_equal(gx, np.array(ref["X"][b * B:(b + 1) * B])) and \
+            np.array_equal(gy, np.array(ref["Y"][b * B:(b + 1) * B], np.float32))
+    assert data["X"] == ref["X"] and data["Y"] == ref["Y"]                 # shuffled in place, like the reference
+    # test(): a forward that returns values outside the label range
+    preds = rng.standard_normal(n).astype(np.float32) * 3
+    m._forward = lambda x_, mask=None: torch.from_numpy(preds).to(dev).reshape(-1, 1)
+    res = quiet(m.test, {"X": X, "Y": Y})
+    y_true = np.reshape(Y, (n,))
+    bounded = np.minimum(np.maximum(preds.astype(np.float64), np.ones(n) * min(y_true)), np.ones(n) * max(y_true))
+    assert abs(res["RMSE"] - math.sqrt(np.mean((y_true - bounded) ** 2))) <= 1e-12
+    assert (np.abs(preds) > 1).any()
+
+
+def test_seq_models_negative_pools_and_device_samplers(dev, tmp_path):
+    """Host samplers draw for draw against the reference's loops restated (AttRec.py:448-466 pools = all items minus
+    the sample's targets; Caser.py:243,302-319 pools = neg_items[u], in the reference's storage-order alignment and in
+    the intended one); sampler="device" gives negatives from the same pools without host loops."""
+    from deeprec_amd.models.seq_rec.AttRec import AttRec
+    from deeprec_amd.models.seq_rec.Caser import Caser
+    from deeprec_amd.models.seq_rec.PRME import PRME
+    rng = np.random.default_rng(15)
+    train, test = _seq_dataset(tmp_path, rng, nu=20, ni=35, L=3, T=2)
+    ni = train.num_item
+    all_items = set(np.arange(ni - 1) + 1)
+    csr = train.tocsr()
+    neg_ref = {u: sorted(all_items - set(csr[u].indices)) for u in range(train.num_user)}
+
+    def run(cls, build_kw, sampler):
+        m = quiet(cls, None, train.num_user, ni, 0.01, 0.01, 1, 16, sampler=sampler)
+        quiet(m.build_network, 3 if cls is not PRME else 1, 2, **build_kw)
+        quiet(m.prepare_data, train, test)
+        got = []
+        rec = lambda u_, s_, t_, n_: got.append((u_.cpu().numpy(), t_.cpu().numpy(), n_.cpu().numpy())) or torch.zeros(1)
+        m.train_op = rec
+        m._step = rec
+        np.random.seed(3)
+        if cls is PRME:
+            quiet(m.train, train)
+        else:
+            quiet(m.train, train)
+        return m, got
+    # AttRec (and PRME, same code): pool = all items minus the sample's own targets
+    m, got = run(AttRec, dict(num_factor=8), "reference")
+    np.random.seed(3)
+    idxs = np.random.permutation(len(m.sequences))
+    tar = m.targets[idxs]
+    want = np.zeros((len(tar), 2))
+    for r in range(len(tar)):
+        pool = sorted(all_items - set(int(t) for t in tar[r]))
+        for j_ in range(2):
+            want[r, j_] = pool[np.random.randint(len(pool))]
+    negs = np.concatenate([g[2] for g in got])
+    assert np.array_equal(negs, want[:len(negs)].astype(np.int32)) and len(negs) >= 32
+    # Caser: pool = neg_items[u]; both alignments
+    for align in ("reference", "intended"):
+        m, got = run(Caser, dict(num_factor=8, n_h=2, n_v=1, num_neg=1, neg_alignment=align), "reference")
+        np.random.seed(3)
+        idxs = np.random.permutation(len(m.sequences))
+        users = m.users[:, 0] if align == "reference" else m.users[idxs][:, 0]
+        want = np.zeros((len(users), 2))
+        for r, u in enumerate(users):
+            for j_ in range(2):
+                x = neg_ref[int(u)]
+                want[r, j_] = x[np.random.randint(len(x))]
+        negs = np.concatenate([g[2] for g in got])
+        assert np.array_equal(negs, want[:len(negs)].astype(np.int32)), align
+    # device samplers: same pools, no host loop
+    for cls, kw in ((AttRec, dict(num_factor=8)), (PRME, dict(num_factor=8)),
+                    (Caser, dict(num_factor=8, n_h=2, n_v=1, num_neg=1))):
+        m, got = run(cls, kw, "device")
+        assert len(got) >= 2
+        for u_, t_, n_ in got:
+            assert n_.shape == (16, 2) and ((n_ >= 1) & (n_ < ni)).all()
+            for r in range(16):
+                if cls is Caser:
+                    assert not np.isin(n_[r], csr[int(u_[r])].indices).any()
+                else:
+                    assert not np.isin(n_[r], t_[r]).any()

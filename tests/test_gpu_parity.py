@@ -777,6 +777,33 @@ def test_sample_negatives_matches_oracle(dev, first):
         assert not np.isin(ok, lists[users[e]]).any() and (ok >= first).all() and (ok < ni).all()
 
 
+@pytest.mark.parametrize("first,Tn", [(1, 3), (0, 1), (1, 16), (1, 0)])
+def test_sample_negatives_excl_matches_oracle(dev, first, Tn):
+    """dr_sample_negatives_excl_i32 (AttRec.py:448-466: pool = all items minus the sample's own targets) == the oracle's
+    list-building restatement, bit for bit; duplicated, padded (0) and out-of-range targets included."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(5 + Tn)
+    ni, n = 211, 3000
+    tg = rng.integers(first, ni, (n, Tn)).astype(np.int32)
+    if Tn >= 3:
+        tg[::7, 1] = tg[::7, 0]                          # a repeated target counts once
+        tg[::11, 2] = 0                                  # the pad item is outside the pool when first_item = 1
+        tg[::13, 0] = ni + 3                             # out of range: ignored
+    got = N(K.sample_negatives_excl(T(tg, dev), ni, seed=9, offset=17, n_neg=4, first_item=first))
+    want = co.sample_negatives_excl(tg, ni, 9, 17, 4, first)
+    assert np.array_equal(got, want)
+    assert ((got >= first) & (got < ni)).all()
+    for e in range(0, n, 29):
+        assert not np.isin(got[e], tg[e]).any()
+    if Tn == 3:                                          # uniform over the pool
+        one = np.tile(np.array([[5, 6, 7]], np.int32), (1 << 16, 1))
+        g = N(K.sample_negatives_excl(T(one, dev), 40, seed=1))[:, 0]
+        cnt = np.bincount(g, minlength=40)
+        assert cnt[[0, 5, 6, 7]].sum() == 0
+        exp = (1 << 16) / 36
+        assert np.abs(np.delete(cnt, [0, 5, 6, 7]) - exp).max() < 6 * np.sqrt(exp)
+
+
 def test_sample_negatives_is_uniform_over_unseen(dev):
     from deeprec_amd import kernels as K
     ni = 64
