@@ -83,6 +83,9 @@ SIGNATURES = {
     "dr_caser_hconv_pool_f32": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "dr_caser_hconv_backward_input_f32": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
     "dr_caser_hconv_backward_filter_f32": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
+    "dr_seq_dist_loss_f32": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _i32, _f, _f, _i32, _f, _p, _p,
+                                    _p, _p, _p, _p]),
+    "dr_seq_dot_loss_f32": (_i32, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _i32, _i32, _f, _p, _p, _p, _p, _p]),
     "dr_profile_enable": (_i32, [_i32]),
     "dr_profile_collect": (_i32, [C.c_char_p, _i64, C.POINTER(C.c_float), _i32]),
 }

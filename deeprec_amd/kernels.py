@@ -680,6 +680,54 @@ def caser_hconv_backward(e, W, arg, gout, C):
     return ge, gW, gbias
 
 
+# ------------------------------------------------------------------ sequence models: interaction + loss
+SEQ_LOSS_HINGE, SEQ_LOSS_BPR = 0, 1
+SEQ_MAX_SLOTS = 64
+
+
+def seq_dist_loss(P, X, Q, users, o, tgt, neg, alpha, beta, loss_kind, margin=0.5):
+    """dr_seq_dist_loss_f32 -> (loss_b [B], gX [B,2T,k], gQ [B,2T,k], gp [B,k], go [B,k])."""
+    P, X, Q = _req(P, torch.float32, "P", 2), _req(X, torch.float32, "X", 2), _req(Q, torch.float32, "Q", 2)
+    o = _req(o, torch.float32, "o", 2)
+    users = _i32(users, "users")
+    tgt, neg = _req(tgt, torch.int32, "tgt", 2), _req(neg, torch.int32, "neg", 2)
+    B, k = o.shape
+    T = tgt.shape[1]
+    if X.shape != Q.shape or X.shape[1] != k or P.shape[1] != k or users.numel() != B or tgt.shape != (B, T) \
+            or neg.shape != (B, T):
+        raise ValueError("seq_dist_loss: P [U,k], X / Q [I,k], users [B], o [B,k], tgt / neg [B,T] expected")
+    dev = o.device
+    loss_b = torch.empty(B, dtype=torch.float32, device=dev)
+    gX = torch.empty((B, 2 * T, k), dtype=torch.float32, device=dev)
+    gQ = torch.empty_like(gX)
+    gp = torch.empty((B, k), dtype=torch.float32, device=dev)
+    go = torch.empty_like(gp)
+    check(_abi.lib().dr_seq_dist_loss_f32(_ptr(P), P.shape[0], _ptr(X), _ptr(Q), X.shape[0], k, _ptr(users), _ptr(o),
+                                          _ptr(tgt), _ptr(neg), B, T, float(alpha), float(beta), int(loss_kind),
+                                          float(margin), _ptr(loss_b), _ptr(gX), _ptr(gQ), _ptr(gp), _ptr(go), _stream()),
+          "dr_seq_dist_loss_f32")
+    return loss_b, gX, gQ, gp, go
+
+
+def seq_dot_loss(W, bias, x, tgt, neg, scale=1.0):
+    """dr_seq_dot_loss_f32 -> (loss_b [B], gW [B,T+Tn,D], gb [B,T+Tn], gx [B,D])."""
+    W, bias, x = _req(W, torch.float32, "W", 2), _req(bias, torch.float32, "bias", 1), _req(x, torch.float32, "x", 2)
+    tgt, neg = _req(tgt, torch.int32, "tgt", 2), _req(neg, torch.int32, "neg", 2)
+    B, D = x.shape
+    T, Tn = tgt.shape[1], neg.shape[1]
+    if W.shape[1] != D or bias.numel() != W.shape[0] or tgt.shape[0] != B or neg.shape[0] != B:
+        raise ValueError("seq_dot_loss: W [I,D], bias [I], x [B,D], tgt [B,T], neg [B,Tn] expected")
+    dev = x.device
+    loss_b = torch.empty(B, dtype=torch.float32, device=dev)
+    gW = torch.empty((B, T + Tn, D), dtype=torch.float32, device=dev)
+    gb = torch.empty((B, T + Tn), dtype=torch.float32, device=dev)
+    gx = torch.empty((B, D), dtype=torch.float32, device=dev)
+    check(_abi.lib().dr_seq_dot_loss_f32(_ptr(W), _ptr(bias), W.shape[0], D, _ptr(x), _ptr(tgt), _ptr(neg), B, T, Tn,
+                                         float(scale), _ptr(loss_b), _ptr(gW), _ptr(gb), _ptr(gx), _stream()),
+          "dr_seq_dot_loss_f32")
+    return loss_b, gW, gb, gx
+
+
 # ------------------------------------------------------------------ K6
 def _csr(ptr, idx, Nu, name):
     if ptr is None:

@@ -566,6 +566,64 @@ def attn_seq(v, timing, W):
     return _AttnSeq.apply(v, timing, W)
 
 
+class _SeqDistLoss(torch.autograd.Function):
+    """Two-distance interaction + pairwise loss fused with the item / user lookups (dr_seq_dist_loss_f32): the
+    forward launches ONE kernel that also produces every gradient; the backward records the gradient rows of the
+    tables X, Q, P for the segment update and hands d loss / d o back to autograd.
+
+    The result must be the tensor backward() is called on (as the reference's `minimize(self.loss)` does,
+    AttRec.py:110, PRME.py:98): the recorded rows are d loss / d row as they stand -- the incoming gradient (1) is not
+    read back from the device, so that the step stays free of host synchronisation and replays as a hipGraph."""
+
+    @staticmethod
+    def forward(ctx, o, tP, tX, tQ, users, tgt, neg, alpha, kind, margin):
+        loss_b, gX, gQ, gp, go = K.seq_dist_loss(tP.w, tX.w, tQ.w, users, o.contiguous(), tgt, neg, alpha, 1.0 - alpha,
+                                                 kind, margin)
+        ctx.tabs, ctx.ids = (tP, tX, tQ), (users, torch.cat((tgt, neg), 1).reshape(-1))
+        ctx.save_for_backward(gX, gQ, gp, go)
+        return K.sum_f32(loss_b).reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        gX, gQ, gp, go = ctx.saved_tensors
+        tP, tX, tQ = ctx.tabs
+        users, items = ctx.ids
+        k = gp.shape[1]
+        tX.pending.append((items, gX.reshape(-1, k)))
+        tQ.pending.append((items, gQ.reshape(-1, k)))
+        tP.pending.append((users, gp))
+        return (go,) + (None,) * 9
+
+
+def seq_dist_loss(o, tP, tX, tQ, users, tgt, neg, alpha, kind, margin=0.5):
+    """Scalar loss of the two-distance models; `o` [B, k] is an autograd tensor (attention output / previous-item rows),
+    tP / tX / tQ are Tables whose gradients are recorded like lookup backwards.  Call backward() on the result."""
+    return _SeqDistLoss.apply(o, tP, tX, tQ, users, tgt, neg, float(alpha), int(kind), float(margin))
+
+
+class _SeqDotLoss(torch.autograd.Function):
+    """Caser's score + mean BCE fused with the W / b lookups (dr_seq_dot_loss_f32); same contract as _SeqDistLoss."""
+
+    @staticmethod
+    def forward(ctx, x, tW, tb, tgt, neg, scale):
+        loss_b, gW, gb, gx = K.seq_dot_loss(tW.w, tb.w, x.contiguous(), tgt, neg, scale)
+        ctx.tabs, ctx.items = (tW, tb), torch.cat((tgt, neg), 1).reshape(-1)
+        ctx.save_for_backward(gW, gb, gx)
+        return K.sum_f32(loss_b).reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        gW, gb, gx = ctx.saved_tensors
+        tW, tb = ctx.tabs
+        tW.pending.append((ctx.items, gW.reshape(-1, gW.shape[2])))
+        tb.pending.append((ctx.items, gb.reshape(-1)))
+        return (gx, None, None, None, None, None)
+
+
+def seq_dot_loss(x, tW, tb, tgt, neg, scale=1.0):
+    return _SeqDotLoss.apply(x, tW, tb, tgt, neg, float(scale))
+
+
 def bi_interaction(table, feats):
     return _BiInteraction.apply(table._hook, table, feats)
 

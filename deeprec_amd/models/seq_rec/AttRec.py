@@ -13,7 +13,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate1
-from .._common import (GraphedStep, TFOptimizer, Table, attn_seq, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
+from .._common import (GraphedStep, TFOptimizer, Table, attn_seq, seq_dist_loss, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 from ._seq_common import SeqBase
 
 
@@ -74,6 +74,7 @@ class AttRec(SeqBase):
             Wp = (torch.rand((d, d), device=dev) * 2 - 1) * lim
         self.linear_project = Wp.requires_grad_(True)
         self._timing = None
+        self.unfused = False        # True: distances / hinge as library elementwise ops under autograd
         self.optimizer = TFOptimizer("adagrad", self.learning_rate, initial_accumulator_value=0.05)
         # hipGraph replay pays off while the step is launch-bound (the reference's B = 1000, L = 5: ~80 short launches);
         # at C5 (B = 4096, L = 50) the kernels fill the GPU and the eager loop is faster (2.52 vs 2.69 ms).  The sharded
@@ -111,10 +112,15 @@ class AttRec(SeqBase):
     def train_op(self, user_id, item_seq, item_id, neg_item_id):
         self.linear_project.grad = None
         out, _ = self._seq_out(item_seq)
-        u = self.P.lookup(user_id)
-        target = self._distance(out, user_id, item_id, u)
-        negative = self._distance(out, user_id, neg_item_id, u)
-        loss = torch.clamp(target - negative + 0.5, min=0).sum()
+        if (self.shard is None and item_id.shape == neg_item_id.shape and 2 * item_id.shape[1] <= K.SEQ_MAX_SLOTS
+                and not self.unfused):
+            # lookups of P, X, Q rows, both distances, the hinge and every gradient in one kernel (AttRec.py:97,190-232)
+            loss = seq_dist_loss(out, self.P, self.X, self.Q, user_id, item_id, neg_item_id, self.alpha, K.SEQ_LOSS_HINGE, 0.5)
+        else:
+            u = self.P.lookup(user_id)
+            target = self._distance(out, user_id, item_id, u)
+            negative = self._distance(out, user_id, neg_item_id, u)
+            loss = torch.clamp(target - negative + 0.5, min=0).sum()
         loss.backward()
         if self.shard:
             self.shard.all_reduce_grads([self.linear_project])

@@ -14,7 +14,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate_caser
-from .._common import (TFOptimizer, Table, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
+from .._common import (TFOptimizer, Table, seq_dot_loss, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 from ._seq_common import SeqBase
 
 
@@ -137,6 +137,7 @@ class Caser(SeqBase):
         self.full_w, self.full_b = dense("full_w", (fin, d), 1.0), dense("full_b", (d,), 0)
         self.fc1_dim_v, self.fc1_dim_h = n_v * d, n_h * d
         self.optimizer = TFOptimizer("adam", self.learning_rate, eps=1e-8)
+        self.unfused = False        # True: score / BCE as library elementwise ops under autograd
         return self
 
     def _dense_params(self):
@@ -159,10 +160,14 @@ class Caser(SeqBase):
         for p in self._dense_params():
             p.grad = None
         x = self._user_emb(item_seq, user_id)
-        target, negative = self._score(x, item_id), self._score(x, neg_item_id)
-        loss = -torch.log(torch.sigmoid(target) + 1e-10).mean() - torch.log(1 - torch.sigmoid(negative) + 1e-10).mean()
-        if self.shard:
-            loss = loss / self.shard.world      # the loss is a batch MEAN: each rank holds 1/world of the batch
+        if (self.shard is None and item_id.shape[1] + neg_item_id.shape[1] <= K.SEQ_MAX_SLOTS and not self.unfused):
+            # lookups of W, b rows, the scores, the mean BCE and every gradient in one kernel (Caser.py:79-80,184-192)
+            loss = seq_dot_loss(x, self.W, self.b, item_id, neg_item_id)
+        else:
+            target, negative = self._score(x, item_id), self._score(x, neg_item_id)
+            loss = -torch.log(torch.sigmoid(target) + 1e-10).mean() - torch.log(1 - torch.sigmoid(negative) + 1e-10).mean()
+            if self.shard:
+                loss = loss / self.shard.world      # the loss is a batch MEAN: each rank holds 1/world of the batch
         loss.backward()
         if self.shard:
             self.shard.all_reduce_grads(self._dense_params())

@@ -10,7 +10,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation import SeqRecMetrics
-from .._common import (TFOptimizer, Table, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
+from .._common import (TFOptimizer, Table, seq_dist_loss, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 from ._seq_common import SeqBase
 
 
@@ -44,6 +44,7 @@ class PRME(SeqBase):
         self.P, self.V = tab("P", self.num_user), tab("V", self.num_user)
         self.Q, self.X = tab("Q", self.num_item), tab("X", self.num_item)
         self.optimizer = TFOptimizer("adam", self.learning_rate, eps=1e-8)
+        self.unfused = False        # True: the distances / loss as library elementwise ops under autograd (what the fused kernel is tested against)
         return self
 
     def _distance(self, item_seq, user_id, item_id):
@@ -53,9 +54,14 @@ class PRME(SeqBase):
         return 0.2 * ((w_items - u) ** 2).sum(2) + 0.8 * ((out[:, None, :] - w_items_2) ** 2).sum(2)
 
     def train_op(self, user_id, item_seq, item_id, neg_item_id):
-        target = self._distance(item_seq, user_id, item_id)
-        negative = self._distance(item_seq, user_id, neg_item_id)
-        loss = -torch.log(torch.sigmoid(-target + negative)).sum()
+        if item_id.shape == neg_item_id.shape and 2 * item_id.shape[1] <= K.SEQ_MAX_SLOTS and not self.unfused:
+            # lookups of X, Q rows, both distances, BPR on distances and every gradient in one kernel (PRME.py:73,104-131)
+            out = self.Q.lookup(item_seq)[:, 0, :]
+            loss = seq_dist_loss(out, self.P, self.X, self.Q, user_id, item_id, neg_item_id, 0.2, K.SEQ_LOSS_BPR)
+        else:
+            target = self._distance(item_seq, user_id, item_id)
+            negative = self._distance(item_seq, user_id, neg_item_id)
+            loss = -torch.log(torch.sigmoid(-target + negative)).sum()
         loss.backward()
         o = self.optimizer
         o.begin_step()

@@ -393,6 +393,29 @@ int32_t dr_caser_hconv_backward_input_f32(const float* gout, const int32_t* arg,
 int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const int32_t* arg, const float* e, int64_t B, int32_t L,
                                            int32_t C, int32_t d, int32_t S, float* partial, void* stream);
 
+/* ---- interaction + loss of the sequence models, fused with their item lookups ------------
+ * dr_seq_dist_loss_f32 replaces the lookups, squared distances, loss and their backward of AttRec.py:190-232 + :97 and
+ * PRME.py:104-131 + :73:  s(b, i) = alpha * ||X[i] - P[users[b]]||^2 + beta * ||o[b] - Q[i]||^2  (beta = 1 - alpha; o =
+ * the sequence representation [B, k]: AttRec's attention output, PRME's previous-item row);
+ *   loss_kind 0: sum_t max(s(b, tgt[b,t]) - s(b, neg[b,t]) + margin, 0)     (AttRec.py:97; gradient 1 where >= 0)
+ *   loss_kind 1: -sum_t log(sigmoid(-s(b, tgt[b,t]) + s(b, neg[b,t])))      (PRME.py:73)
+ * tgt, neg int32 [B, T] (pair t = target t with negative t; 2 T <= 64).  Outputs: loss_b [B];
+ * gX, gQ [B, 2T, k] = d loss / d X[item], d loss / d Q[item] per (sample, slot), slots = the T targets then the T
+ * negatives (feed them to the segment update with ids [tgt | neg] row by row); gp [B, k] = d loss / d P[users[b]];
+ * go [B, k] = d loss / d o[b].  A pair with an id out of range contributes nothing.
+ * dr_seq_dot_loss_f32 is the same stage of Caser (Caser.py:79-80,184-192): s(b, i) = <x[b], W[i]> + bias[i] over D
+ * columns, loss = scale * (-mean_{b,t} log(sigmoid(s_tgt) + 1e-10) - mean_{b,t} log(1 - sigmoid(s_neg) + 1e-10))
+ * (the means over B T resp. B Tn entries; scale = 1 / world for a data-parallel slice of the batch); outputs loss_b [B]
+ * (its sum is the loss), gW [B, T+Tn, D], gb [B, T+Tn], gx [B, D]. */
+int32_t dr_seq_dist_loss_f32(const float* P, int64_t num_user, const float* X, const float* Q, int64_t num_item,
+                             int32_t k, const int32_t* users, const float* o, const int32_t* tgt,
+                             const int32_t* neg, int64_t B, int32_t T, float alpha, float beta,
+                             int32_t loss_kind, float margin, float* loss_b, float* gX, float* gQ, float* gp,
+                             float* go, void* stream);
+int32_t dr_seq_dot_loss_f32(const float* W, const float* bias, int64_t num_item, int32_t D, const float* x,
+                            const int32_t* tgt, const int32_t* neg, int64_t B, int32_t T, int32_t Tn,
+                            float scale, float* loss_b, float* gW, float* gb, float* gx, void* stream);
+
 /* ---- row-sharded BPR step: routing helpers (no counterpart in the reference; SURVEY 8e, deeprec_amd/sharding.py) ----
  * A sample (u, i, j) of rank r's batch is processed by the rank that owns P[u] (u % world); that rank fetches the
  * distinct Q rows its samples need from their owners (row % world), and sends the item-side gradient rows back.
