@@ -72,9 +72,7 @@ SIGNATURES = {
     "dr_bucket_order_bytes": (_i64, [_i64]),
     "dr_bucket_order_i32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "dr_route_bytes": (_i64, [_i64]),
-    "dr_route_samples_i32": (_i32, [_p, _p, _p, _i64, _i32, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
-    "dr_route_items_i32": (_i32, [_p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
-    "dr_canon_contributions_i32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "dr_route_views_i32": (_i32, [_p, _i32, _i64, _i32, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "dr_bpr_item_grads_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _p]),
     "dr_mlp_forward_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "dr_mlp_backward_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -8,25 +8,30 @@ char* last_error_buf() {
     return buf;
 }
 
-// resident blocks of `kernel` on the current device (occupancy x compute units), cached per kernel and host thread
+// resident blocks of `kernel` on the current device (occupancy x compute units), cached per (device, kernel) and host
+// thread
 int occupancy_blocks(const void* kernel, int block) {
     struct Entry {
         const void* k;
-        int blocks;
+        int dev, blocks;
     };
-    static thread_local Entry cache[64];
+    static thread_local Entry cache[128];
     static thread_local int used = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
     for (int e = 0; e < used; ++e)
-        if (cache[e].k == kernel) return cache[e].blocks;
-    int per_cu = 0, dev = 0, cus = 0;
+        if (cache[e].k == kernel && cache[e].dev == dev) return cache[e].blocks;
+    int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu <= 0 ||
-        hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
         (void)hipGetLastError();
         return 0;
     }
     const int blocks = per_cu * cus;
-    if (used < 64) cache[used++] = Entry{kernel, blocks};
+    if (used < 128) cache[used++] = Entry{kernel, dev, blocks};
     return blocks;
 }
 

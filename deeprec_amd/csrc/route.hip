@@ -49,116 +49,128 @@ static unsigned bits_for(uint64_t max_value) {  // radix bits that cover 0 .. ma
 
 constexpr int MAX_WORLD = 64;
 
-// ---- samples -> the rank that owns their user row -------------------------------------------------------
-// key = u % W (bucket W: a sample with any id out of range; sorts last, counted apart, never sent)
-__global__ __launch_bounds__(256) void route_sample_keys_kernel(const int32_t* __restrict__ u,
-                                                                const int32_t* __restrict__ i,
-                                                                const int32_t* __restrict__ j, int64_t B, int W,
-                                                                int64_t nu, int64_t ni, uint32_t* __restrict__ keys,
-                                                                int32_t* __restrict__ vals,
-                                                                unsigned long long* __restrict__ counts) {
-    __shared__ int hist[MAX_WORLD + 1];
-    for (int b = threadIdx.x; b <= W; b += 256) hist[b] = 0;
-    __syncthreads();
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < B; e += (int64_t)gridDim.x * 256) {
-        const int64_t uu = u[e], ii = i[e], jj = j[e];
-        const bool ok = uu >= 0 && uu < nu && ii >= 0 && ii < ni && jj >= 0 && jj < ni;
-        const int b = ok ? (int)(uu % W) : W;
-        keys[e] = (uint32_t)b;
-        vals[e] = (int32_t)e;
-        atomicAdd(&hist[b], 1);
+// ---- both roles of a rank, derived from the replicated id lists ----------------------------------------------
+// ids = [W][3][B]: rank s's (u, i, j) lists (one fixed-size all-gather).  The global batch is the concatenation in rank
+// order; global sample g = s * B + position.  List entry e in [0, 2 W B): part = e / (W B) (0: item i, 1: item j),
+// sample g = e % (W B) -- ascending e IS the canonical contribution order of a single process (i-part before j-part,
+// then global batch position).  Two views of the same list, sorted in one pass (view bit above the key):
+//   view 0 (processing rank): entries of samples with u % W == me, key = owner(item) * rpo + item / W
+//   view 1 (row owner):       entries with item % W == me,         key = (u % W)     * rpo + item / W
+// Entries that do not belong to a view get the view's sentinel key (sorts behind the view's real keys).  A stable sort
+// then leaves, per view and per major (owner resp. processing rank), rows ascending and equal rows in canonical order:
+// exactly the order the sender packs and the receiver expects, so no ids, requests or metadata ever travel.
+struct ViewArgs {
+    const int32_t* ids;
+    int64_t B, WB;
+    int W, me;
+    int64_t nu, ni;
+    uint32_t rpo, sentinel;  // sentinel = W * rpo; view 1 keys are offset by sentinel + 1
+};
+
+__device__ __forceinline__ bool view_entry(const ViewArgs& a, int64_t x, uint32_t* key, int32_t* u_out) {
+    // x in [0, 4 W B): view = x / (2 W B), e = x % (2 W B)
+    const int view = x >= 2 * a.WB;
+    const int64_t e = x - (view ? 2 * a.WB : 0);
+    const int part = e >= a.WB;
+    const int64_t g = e - (part ? a.WB : 0);
+    const int64_t s = g / a.B, pos = g - s * a.B;
+    const int32_t* base = a.ids + s * 3 * a.B;
+    const int64_t uu = base[pos], ii = base[a.B + pos], jj = base[2 * a.B + pos];
+    const bool ok = uu >= 0 && uu < a.nu && ii >= 0 && ii < a.ni && jj >= 0 && jj < a.ni;
+    const uint32_t item = (uint32_t)(part ? jj : ii);
+    const uint32_t r = ok ? (uint32_t)(uu % a.W) : 0u, o = ok ? item % (uint32_t)a.W : 0u;
+    const bool mine = ok && (view ? o == (uint32_t)a.me : r == (uint32_t)a.me);
+    const uint32_t major = view ? r : o;
+    *key = (view ? a.sentinel + 1u : 0u) + (mine ? major * a.rpo + item / (uint32_t)a.W : a.sentinel);
+    *u_out = (int32_t)uu;
+    return mine;
+}
+
+// keys + values of the 4 W B list entries; counts[4 W + 2] = samples (of the GLOBAL batch) with an id out of range
+__global__ __launch_bounds__(256) void view_keys_kernel(ViewArgs a, uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                        int32_t* __restrict__ flags,
+                                                        unsigned long long* __restrict__ counts) {
+    int bad = 0;
+    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < 4 * a.WB; x += (int64_t)gridDim.x * 256) {
+        uint32_t key;
+        int32_t uu;
+        const bool mine = view_entry(a, x, &key, &uu);
+        keys[x] = key;
+        vals[x] = (int32_t)x;
+        flags[x] = mine ? 1 : 0;
+        if (x < a.WB) {  // validity once per sample
+            const int64_t s = x / a.B, pos = x - s * a.B;
+            const int32_t* base = a.ids + s * 3 * a.B;
+            const int64_t ii = base[a.B + pos], jj = base[2 * a.B + pos];
+            if (!(uu >= 0 && uu < a.nu && ii >= 0 && ii < a.ni && jj >= 0 && jj < a.ni)) ++bad;
+        }
     }
-    __syncthreads();
-    for (int b = threadIdx.x; b <= W; b += 256)
-        if (hist[b]) atomicAdd(&counts[b], (unsigned long long)hist[b]);
+    if (bad) atomicAdd(&counts[4 * a.W + 2], (unsigned long long)bad);  // rare: a refused batch
 }
 
-// tuples in wire order: (local user row, item i, item j, tag + batch position)
-__global__ __launch_bounds__(256) void route_sample_pack_kernel(const int32_t* __restrict__ order,
-                                                                const int32_t* __restrict__ u,
-                                                                const int32_t* __restrict__ i,
-                                                                const int32_t* __restrict__ j, int64_t B, int W,
-                                                                int32_t tag, int4* __restrict__ tuples) {
-    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < B; y += (int64_t)gridDim.x * 256) {
-        const int o = order[y];
-        tuples[y] = make_int4(u[o] / W, i[o], j[o], tag + o);
+// heads of the distinct keys of the sorted list (sentinels are never heads)
+__global__ __launch_bounds__(256) void view_heads_kernel(const uint32_t* __restrict__ sk, int64_t n, uint32_t sentinel,
+                                                         int32_t* __restrict__ flags) {
+    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < n; y += (int64_t)gridDim.x * 256) {
+        const uint32_t k = sk[y];
+        const bool real = k != sentinel && k != 2u * sentinel + 1u;
+        flags[y] = (real && (y == 0 || k != sk[y - 1])) ? 1 : 0;
     }
 }
 
-// ---- the item rows a processing rank needs, and where its gradient contributions go -------------------
-// list entry e < n: item i of sample e; e >= n: item j of sample e - n.  okey = owner * rpo + local row.
-__global__ __launch_bounds__(256) void route_item_keys_kernel(const int4* __restrict__ smp, int64_t n, int W,
-                                                              uint32_t rpo, uint32_t* __restrict__ keys,
-                                                              int32_t* __restrict__ vals, int32_t* __restrict__ u_loc,
-                                                              unsigned long long* __restrict__ counts) {
-    __shared__ int hist[MAX_WORLD];
-    for (int b = threadIdx.x; b < W; b += 256) hist[b] = 0;
+// per view v (outputs at offset v * 2 W B): c = compacted canonical index of the entry, y = its position in the view's
+// sorted list, seg = index of its distinct (major, row):
+//   rows[c] = local row, inv[c] = seg, order[y] = c, perm[c] = y, uniq[seg] = row, u_loc[c] = u / W (view 0, part 0)
+// counts[2 (v W + major)] += distinct, counts[2 (v W + major) + 1] += entries; counts[4 W + v] = entries of the view
+__global__ __launch_bounds__(256) void view_pack_kernel(ViewArgs a, const uint32_t* __restrict__ sk,
+                                                        const int32_t* __restrict__ sv, const int32_t* __restrict__ cidx,
+                                                        const int32_t* __restrict__ heads, const int32_t* __restrict__ segidx,
+                                                        int32_t* __restrict__ u_loc, int32_t* __restrict__ rows,
+                                                        int32_t* __restrict__ inv, int32_t* __restrict__ order,
+                                                        int32_t* __restrict__ perm, int32_t* __restrict__ uniq,
+                                                        unsigned long long* __restrict__ counts) {
+    __shared__ int hist[4 * MAX_WORLD];
+    for (int b = threadIdx.x; b < 4 * a.W; b += 256) hist[b] = 0;
     __syncthreads();
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 2 * n; e += (int64_t)gridDim.x * 256) {
-        const int4 t = smp[e < n ? e : e - n];
-        const uint32_t id = (uint32_t)(e < n ? t.y : t.z);
-        const uint32_t o = id % (uint32_t)W;
-        keys[e] = o * rpo + id / (uint32_t)W;
-        vals[e] = (int32_t)e;
-        if (e < n) u_loc[e] = t.x;
-        atomicAdd(&hist[o], 1);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < W; b += 256)
-        if (hist[b]) atomicAdd(&counts[2 * b + 1], (unsigned long long)hist[b]);
-}
-
-__global__ __launch_bounds__(256) void route_heads_kernel(const uint32_t* __restrict__ sk, int64_t n,
-                                                          int32_t* __restrict__ flags) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
-        flags[e] = (e == 0 || sk[e] != sk[e - 1]) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void route_item_pack_kernel(const uint32_t* __restrict__ sk,
-                                                              const int32_t* __restrict__ order,
-                                                              const int32_t* __restrict__ flags,
-                                                              const int32_t* __restrict__ segidx,
-                                                              const int4* __restrict__ smp, int64_t n, int W,
-                                                              uint32_t rpo, int part_bit, int32_t* __restrict__ inv,
-                                                              int32_t* __restrict__ uniq_rows,
-                                                              int2* __restrict__ meta,
-                                                              unsigned long long* __restrict__ counts) {
-    __shared__ int hist[MAX_WORLD];
-    for (int b = threadIdx.x; b < W; b += 256) hist[b] = 0;
-    __syncthreads();
-    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < 2 * n; y += (int64_t)gridDim.x * 256) {
-        const uint32_t key = sk[y];
-        const int e = order[y];
-        const int head = flags[y];
-        const int seg = segidx[y] - (head ? 0 : 1);
-        const uint32_t o = key / rpo;
-        const int32_t row = (int32_t)(key - o * rpo);
-        inv[e] = seg;
-        const int gpos = e < n ? smp[e].w : (smp[e - n].w | (1 << part_bit));
-        meta[y] = make_int2(row, gpos);
+    const int64_t half = 2 * a.WB;
+    const int32_t c1 = cidx[half], s1 = segidx[half];  // first compacted index / segment of view 1
+    for (int64_t ys = (int64_t)blockIdx.x * 256 + threadIdx.x; ys < 2 * half; ys += (int64_t)gridDim.x * 256) {
+        uint32_t key = sk[ys];
+        const int view = ys >= half;
+        if (view) key -= a.sentinel + 1u;
+        if (key == a.sentinel) continue;
+        const int64_t x = sv[ys];
+        const int64_t off = view ? half : 0;
+        const int32_t c = cidx[x] - (view ? c1 : 0);
+        const int32_t y = (int32_t)(ys - off);
+        const int head = heads[ys];
+        const int32_t seg = segidx[ys] - (head ? 0 : 1) - (view ? s1 : 0);
+        const uint32_t major = key / a.rpo;
+        const int32_t row = (int32_t)(key - major * a.rpo);
+        rows[off + c] = row;
+        inv[off + c] = seg;
+        order[off + y] = c;
+        perm[off + c] = y;
         if (head) {
-            uniq_rows[seg] = row;
-            atomicAdd(&hist[o], 1);
+            uniq[off + seg] = row;
+            atomicAdd(&hist[2 * (view * a.W + (int)major)], 1);
+        }
+        atomicAdd(&hist[2 * (view * a.W + (int)major) + 1], 1);
+        if (!view) {
+            const int64_t e = x;
+            if (e < a.WB) {
+                const int64_t s = e / a.B, pos = e - s * a.B;
+                u_loc[c] = a.ids[s * 3 * a.B + pos] / a.W;
+            }
         }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < W; b += 256)
-        if (hist[b]) atomicAdd(&counts[2 * b], (unsigned long long)hist[b]);
-}
-
-// ---- owner side: received contributions -> canonical order (ascending global key) ------------------------
-__global__ __launch_bounds__(256) void canon_keys_kernel(const int2* __restrict__ meta, int64_t n,
-                                                         uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        keys[e] = (uint32_t)meta[e].y;
-        vals[e] = (int32_t)e;
+    for (int b = threadIdx.x; b < 4 * a.W; b += 256)
+        if (hist[b]) atomicAdd(&counts[b], (unsigned long long)hist[b]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counts[4 * a.W] = (unsigned long long)c1;
+        counts[4 * a.W + 1] = (unsigned long long)(cidx[2 * half] - c1);
     }
-}
-
-__global__ __launch_bounds__(256) void canon_ids_kernel(const int2* __restrict__ meta, const int32_t* __restrict__ perm,
-                                                        int64_t n, int32_t* __restrict__ ids) {
-    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < n; y += (int64_t)gridDim.x * 256)
-        ids[y] = meta[perm[y]].x;
 }
 
 // ---- item-side gradient rows in wire order: out[y] = (+-g[s]) * P[u_loc[s]] ----------------------------------
@@ -204,94 +216,65 @@ extern "C" int64_t dr_route_bytes(int64_t n) {
     return L.total;
 }
 
-#define DR_ROUTE_WS(n_, who)                                                                                         \
-    RouteLayout L;                                                                                                   \
-    if (route_layout((n_), &L) != 0) DR_FAIL(DR_ERR_LAUNCH, who ": rocprim size query failed");                      \
-    DR_REQUIRE(ws != nullptr && ((uintptr_t)ws % 256 == 0), who ": ws is NULL / not 256-byte aligned");              \
-    if (ws_bytes < L.total)                                                                                          \
-        DR_FAIL(DR_ERR_WORKSPACE, who ": workspace %lld < dr_route_bytes(%lld) = %lld", (long long)ws_bytes,         \
-                (long long)(n_), (long long)L.total);                                                                \
-    char* base = (char*)ws;                                                                                          \
-    uint32_t* kin = (uint32_t*)(base + L.keys_in);                                                                   \
-    uint32_t* kout = (uint32_t*)(base + L.keys_out);                                                                 \
-    int32_t* vin = (int32_t*)(base + L.vals_in);                                                                     \
-    size_t tb = (size_t)L.temp_bytes
-
-extern "C" int32_t dr_route_samples_i32(const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, int32_t world,
-                                        int64_t num_user, int64_t num_item, int32_t tag, int32_t* tuples,
-                                        int64_t* counts, void* ws, int64_t ws_bytes, void* stream) {
-    DR_REQUIRE(B >= 0 && B < (1ll << 31) - 1 && world >= 1 && world <= MAX_WORLD && num_user >= 0 && num_item >= 0,
-               "dr_route_samples_i32: bad sizes (world in [1,%d])", MAX_WORLD);
-    DR_REQUIRE(counts != nullptr, "dr_route_samples_i32: counts is NULL");
+extern "C" int32_t dr_route_views_i32(const int32_t* ids, int32_t world, int64_t B, int32_t me, int64_t num_user,
+                                      int64_t num_item, int64_t rows_per_owner, int32_t* u_loc, int32_t* rows, int32_t* inv,
+                                      int32_t* order, int32_t* perm, int32_t* uniq, int64_t* counts, void* ws,
+                                      int64_t ws_bytes, void* stream) {
+    DR_REQUIRE(world >= 1 && world <= MAX_WORLD && me >= 0 && me < world && B >= 0 && num_user >= 0 && num_item >= 0 &&
+                   rows_per_owner >= 1 && (uint64_t)world * (uint64_t)rows_per_owner < (1ull << 31) - 1 &&
+                   4 * (int64_t)world * B + 1 < (1ll << 31) - 1,
+               "dr_route_views_i32: bad sizes (world in [1,%d], world * rows_per_owner < 2^31, 4 * world * B < 2^31)",
+               MAX_WORLD);
+    DR_REQUIRE(counts != nullptr, "dr_route_views_i32: counts is NULL");
     hipStream_t st = (hipStream_t)stream;
-    DR_HIP(hipMemsetAsync(counts, 0, (size_t)(world + 1) * 8, st));
+    DR_HIP(hipMemsetAsync(counts, 0, (size_t)(4 * world + 3) * 8, st));
     if (B == 0) return DR_OK;
-    DR_REQUIRE(u && i && j && tuples && ((uintptr_t)tuples % 16 == 0), "dr_route_samples_i32: NULL / misaligned pointer");
-    DR_ROUTE_WS(B, "dr_route_samples_i32");
-    int32_t* order = (int32_t*)(base + L.vals_out);
-    const int grid = grid_for(B, 256);
-    DR_LAUNCH(route_sample_keys_kernel, dim3(grid), dim3(256), 0, st, u, i, j, B, (int)world, num_user, num_item, kin,
-              vin, (unsigned long long*)counts);
-    DR_CHECK_LAUNCH("route_sample_keys_kernel");
-    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, kin, kout, vin, order, (size_t)B, 0u,
-                                                               bits_for((uint64_t)world), st, false)));
-    DR_LAUNCH(route_sample_pack_kernel, dim3(grid), dim3(256), 0, st, (const int32_t*)order, u, i, j, B, (int)world, tag,
-              (int4*)tuples);
-    DR_CHECK_LAUNCH("route_sample_pack_kernel");
-    return DR_OK;
-}
-
-extern "C" int32_t dr_route_items_i32(const int32_t* samples, int64_t n, int32_t world, int64_t rows_per_owner,
-                                      int32_t part_bit, int32_t* u_loc, int32_t* inv, int32_t* uniq_rows, int32_t* meta,
-                                      int32_t* order, int64_t* counts, void* ws, int64_t ws_bytes, void* stream) {
-    DR_REQUIRE(n >= 0 && 2 * n < (1ll << 31) - 1 && world >= 1 && world <= MAX_WORLD && rows_per_owner >= 1 &&
-                   (uint64_t)world * (uint64_t)rows_per_owner < (1ull << 32) && part_bit >= 1 && part_bit <= 30,
-               "dr_route_items_i32: bad sizes");
-    DR_REQUIRE(counts != nullptr, "dr_route_items_i32: counts is NULL");
-    hipStream_t st = (hipStream_t)stream;
-    DR_HIP(hipMemsetAsync(counts, 0, (size_t)world * 16, st));
-    if (n == 0) return DR_OK;
-    DR_REQUIRE(samples && u_loc && inv && uniq_rows && meta && order && ((uintptr_t)samples % 16 == 0) &&
-                   ((uintptr_t)meta % 8 == 0),
-               "dr_route_items_i32: NULL / misaligned pointer");
-    const int64_t m = 2 * n;
-    DR_ROUTE_WS(m, "dr_route_items_i32");
-    int32_t* flags = (int32_t*)(base + L.flags);
-    int32_t* segidx = (int32_t*)(base + L.segidx);
+    DR_REQUIRE(ids && u_loc && rows && inv && order && perm && uniq, "dr_route_views_i32: NULL pointer");
+    const int64_t WB = (int64_t)world * B, m = 4 * WB;
+    RouteLayout L;
+    if (route_layout(m + 1, &L) != 0) DR_FAIL(DR_ERR_LAUNCH, "dr_route_views_i32: rocprim size query failed");
+    DR_REQUIRE(ws != nullptr && ((uintptr_t)ws % 256 == 0), "dr_route_views_i32: ws is NULL / not 256-byte aligned");
+    if (ws_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_route_views_i32: workspace %lld < dr_route_bytes(%lld) = %lld", (long long)ws_bytes,
+                (long long)(m + 1), (long long)L.total);
+    char* base = (char*)ws;
+    uint32_t* kin = (uint32_t*)(base + L.keys_in);
+    uint32_t* kout = (uint32_t*)(base + L.keys_out);
+    int32_t* vin = (int32_t*)(base + L.vals_in);
+    int32_t* vout = (int32_t*)(base + L.vals_out);
+    int32_t* flags = (int32_t*)(base + L.flags);    // m + 1 entries; reused as the scan outputs' input twice
+    int32_t* scan = (int32_t*)(base + L.segidx);    // m + 1 entries
+    size_t tb = (size_t)L.temp_bytes;
+    ViewArgs a;
+    a.ids = ids;
+    a.B = B;
+    a.WB = WB;
+    a.W = world;
+    a.me = me;
+    a.nu = num_user;
+    a.ni = num_item;
+    a.rpo = (uint32_t)rows_per_owner;
+    a.sentinel = (uint32_t)world * (uint32_t)rows_per_owner;
     const int grid = grid_for(m, 256);
-    const uint32_t rpo = (uint32_t)rows_per_owner;
-    DR_LAUNCH(route_item_keys_kernel, dim3(grid), dim3(256), 0, st, (const int4*)samples, n, (int)world, rpo, kin, vin,
-              u_loc, (unsigned long long*)counts);
-    DR_CHECK_LAUNCH("route_item_keys_kernel");
-    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(
-        base + L.temp, tb, kin, kout, vin, order, (size_t)m, 0u,
-        bits_for((uint64_t)world * (uint64_t)rows_per_owner - 1), st, false)));
-    DR_LAUNCH(route_heads_kernel, dim3(grid), dim3(256), 0, st, (const uint32_t*)kout, m, flags);
-    DR_CHECK_LAUNCH("route_heads_kernel");
+    // the compacted canonical index needs its own buffer next to the segment index: it lives in keys_in after the sort
+    DR_LAUNCH(view_keys_kernel, dim3(grid), dim3(256), 0, st, a, kin, vin, flags, (unsigned long long*)counts);
+    DR_CHECK_LAUNCH("view_keys_kernel");
+    DR_HIP(hipMemsetAsync(flags + m, 0, 4, st));
+    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, kin, kout, vin, vout, (size_t)m, 0u,
+                                                               bits_for(2ull * a.sentinel + 1ull), st, false)));
+    int32_t* cidx = (int32_t*)kin;                  // keys_in is free now (m * 4 bytes + the 256-byte pad holds entry m)
     tb = (size_t)L.temp_bytes;
-    DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, segidx, (int32_t)0, (size_t)m,
+    DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, cidx, (int32_t)0, (size_t)(m + 1),
                                                              rocprim::plus<int32_t>(), st, false)));
-    DR_LAUNCH(route_item_pack_kernel, dim3(grid), dim3(256), 0, st, (const uint32_t*)kout, (const int32_t*)order,
-              (const int32_t*)flags, (const int32_t*)segidx, (const int4*)samples, n, (int)world, rpo, (int)part_bit, inv,
-              uniq_rows, (int2*)meta, (unsigned long long*)counts);
-    DR_CHECK_LAUNCH("route_item_pack_kernel");
-    return DR_OK;
-}
-
-extern "C" int32_t dr_canon_contributions_i32(const int32_t* meta, int64_t n, int32_t key_bits, int32_t* ids_canon,
-                                              int32_t* perm, void* ws, int64_t ws_bytes, void* stream) {
-    DR_REQUIRE(n >= 0 && n < (1ll << 31) - 1 && key_bits >= 1 && key_bits <= 31, "dr_canon_contributions_i32: bad sizes");
-    if (n == 0) return DR_OK;
-    DR_REQUIRE(meta && ids_canon && perm && ((uintptr_t)meta % 8 == 0), "dr_canon_contributions_i32: NULL / misaligned pointer");
-    hipStream_t st = (hipStream_t)stream;
-    DR_ROUTE_WS(n, "dr_canon_contributions_i32");
-    const int grid = grid_for(n, 256);
-    DR_LAUNCH(canon_keys_kernel, dim3(grid), dim3(256), 0, st, (const int2*)meta, n, kin, vin);
-    DR_CHECK_LAUNCH("canon_keys_kernel");
-    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, kin, kout, vin, perm, (size_t)n, 0u,
-                                                               (unsigned)key_bits, st, false)));
-    DR_LAUNCH(canon_ids_kernel, dim3(grid), dim3(256), 0, st, (const int2*)meta, (const int32_t*)perm, n, ids_canon);
-    DR_CHECK_LAUNCH("canon_ids_kernel");
+    DR_LAUNCH(view_heads_kernel, dim3(grid), dim3(256), 0, st, (const uint32_t*)kout, m, a.sentinel, flags);
+    DR_CHECK_LAUNCH("view_heads_kernel");
+    tb = (size_t)L.temp_bytes;
+    DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, scan, (int32_t)0, (size_t)(m + 1),
+                                                             rocprim::plus<int32_t>(), st, false)));
+    DR_LAUNCH(view_pack_kernel, dim3(grid), dim3(256), 0, st, a, (const uint32_t*)kout, (const int32_t*)vout,
+              (const int32_t*)cidx, (const int32_t*)flags, (const int32_t*)scan, u_loc, rows, inv, order, perm, uniq,
+              (unsigned long long*)counts);
+    DR_CHECK_LAUNCH("view_pack_kernel");
     return DR_OK;
 }
 

@@ -28,9 +28,19 @@ def _stream():
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
+def _on_current_device(t, name):
+    """Launches go to the CURRENT device's current stream: a tensor of another GPU would be read through that GPU's
+    pointer on the wrong stream (or fault).  One process drives one GPU here; anything else is refused."""
+    cur = torch._C._cuda_getDevice()
+    if t.device.index != cur:
+        raise ValueError("%s lives on %s but the current device is cuda:%d (torch.cuda.set_device first)"
+                         % (name, t.device, cur))
+
+
 def _req(t, dtype, name, ndim=None):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError("%s must be a CUDA/HIP tensor (deeprec_amd has no CPU path)" % name)
+    _on_current_device(t, name)
     if t.dtype != dtype:
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
     if not t.is_contiguous():
@@ -43,6 +53,7 @@ def _req(t, dtype, name, ndim=None):
 def _ids(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError("%s must be a CUDA/HIP tensor" % name)
+    _on_current_device(t, name)
     if t.dtype not in (torch.int32, torch.int64):
         raise TypeError("%s must be int32 or int64, got %s" % (name, t.dtype))
     if not t.is_contiguous():
@@ -194,58 +205,33 @@ def _route_ws(n_keys, device):
     return torch.empty(max(need, 256), dtype=torch.uint8, device=device)
 
 
-def route_samples(u, i, j, world, num_user, num_item, tag):
-    """Samples of one batch -> the rank that owns their user row (deeprec_amd/sharding.py).  Returns
-    (tuples int32 [B,4] = (u // world, i, j, tag + position), bucketed by u % world in batch order;
-    counts int64 [world+1], the last entry counting samples with an id out of range).  No host sync."""
-    B = _i32(u, "u").numel()
-    if _i32(i, "i").numel() != B or _i32(j, "j").numel() != B:
-        raise ValueError("u, i, j must have the same length")
-    tup = torch.empty((B, 4), dtype=torch.int32, device=u.device)
-    counts = torch.empty(world + 1, dtype=torch.int64, device=u.device)
-    ws = _route_ws(B, u.device)
-    check(_abi.lib().dr_route_samples_i32(_ptr(u), _ptr(i), _ptr(j), B, int(world), int(num_user), int(num_item),
-                                          int(tag), _ptr(tup), _ptr(counts), _ptr(ws), ws.numel(), _stream()),
-          "dr_route_samples_i32")
-    return tup, counts
+class RouteViews:
+    """Outputs of route_views (device tensors sized for the worst case; `counts` says how much of each is used)."""
+    __slots__ = ("u_loc", "rows", "inv", "order", "perm", "uniq", "counts", "n_list")
 
 
-class ItemRoute:
-    __slots__ = ("u_loc", "inv", "uniq_rows", "meta", "order", "counts")
-
-
-def route_items(samples, world, rows_per_owner, part_bit):
-    """Received sample tuples [n,4] -> distinct item rows to fetch per owner, the index of every (sample, i|j) entry
-    in that list, and the wire order / metadata of the item-side gradient contributions (include/deeprec_amd.h)."""
-    samples = _req(samples, torch.int32, "samples", 2)
-    n = samples.shape[0]
-    if samples.shape[1] != 4:
-        raise ValueError("samples must be [n,4]")
-    dev = samples.device
-    r = ItemRoute()
-    r.u_loc = torch.empty(n, dtype=torch.int32, device=dev)
-    r.inv = torch.empty(2 * n, dtype=torch.int32, device=dev)
-    r.uniq_rows = torch.empty(2 * n, dtype=torch.int32, device=dev)
-    r.meta = torch.empty((2 * n, 2), dtype=torch.int32, device=dev)
-    r.order = torch.empty(2 * n, dtype=torch.int32, device=dev)
-    r.counts = torch.empty((world, 2), dtype=torch.int64, device=dev)
-    ws = _route_ws(2 * n, dev)
-    check(_abi.lib().dr_route_items_i32(_ptr(samples), n, int(world), int(rows_per_owner), int(part_bit), _ptr(r.u_loc),
-                                        _ptr(r.inv), _ptr(r.uniq_rows), _ptr(r.meta), _ptr(r.order), _ptr(r.counts),
-                                        _ptr(ws), ws.numel(), _stream()), "dr_route_items_i32")
+def route_views(ids, me, num_user, num_item, rows_per_owner):
+    """Both roles of rank `me` in a row-sharded BPR step from the replicated id lists ids [world, 3, B] (int32):
+    dr_route_views_i32 (include/deeprec_amd.h).  Every output except u_loc / counts is [2, 2 world B] (view 0: what this
+    rank processes, view 1: what it owns).  No host synchronisation."""
+    ids = _req(ids, torch.int32, "ids", 3)
+    W, three, B = ids.shape
+    if three != 3:
+        raise ValueError("ids must be [world, 3, B]")
+    dev = ids.device
+    n = 2 * W * B
+    r = RouteViews()
+    r.n_list = n
+    buf = torch.empty((5, 2, max(n, 1)), dtype=torch.int32, device=dev)
+    r.rows, r.inv, r.order, r.perm, r.uniq = buf[0], buf[1], buf[2], buf[3], buf[4]
+    r.u_loc = torch.empty(max(W * B, 1), dtype=torch.int32, device=dev)
+    r.counts = torch.empty(4 * W + 3, dtype=torch.int64, device=dev)
+    ws = _route_ws(2 * n + 1, dev)
+    check(_abi.lib().dr_route_views_i32(_ptr(ids), W, B, int(me), int(num_user), int(num_item), int(rows_per_owner),
+                                        _ptr(r.u_loc), _ptr(r.rows), _ptr(r.inv), _ptr(r.order), _ptr(r.perm),
+                                        _ptr(r.uniq), _ptr(r.counts), _ptr(ws), ws.numel(), _stream()),
+          "dr_route_views_i32")
     return r
-
-
-def canon_contributions(meta, key_bits):
-    """Received (row, global key) pairs [n,2] -> (ids_canon int32 [n], perm int32 [n]): ascending global key."""
-    meta = _req(meta, torch.int32, "meta", 2)
-    n = meta.shape[0]
-    ids = torch.empty(n, dtype=torch.int32, device=meta.device)
-    perm = torch.empty(n, dtype=torch.int32, device=meta.device)
-    ws = _route_ws(n, meta.device)
-    check(_abi.lib().dr_canon_contributions_i32(_ptr(meta), n, int(key_bits), _ptr(ids), _ptr(perm), _ptr(ws),
-                                                ws.numel(), _stream()), "dr_canon_contributions_i32")
-    return ids, perm
 
 
 def bpr_item_grads(P, u_loc, g, order):

@@ -7,21 +7,24 @@ better than contiguous blocks).
 
 A BPR step moves the *sample* to the data where that is cheaper than moving the data to the sample:
 
-    samples (u, i, j, position)  -> the owner of P[u]      16 B per sample   (user rows never travel)
+    id lists (u, i, j)           -> every rank             12 B per sample, ONE fixed-size all-gather
     distinct item rows           <- the owners of Q rows   4k B per DISTINCT item a rank's samples touch
     item gradient rows           -> the owners of Q rows   4k B per (sample, item) contribution
 
-The processing rank (owner of the user row) runs the lookup / dot / loss kernel on its own P shard
-and the fetched Q rows, updates its P rows locally, and ships one gradient row per item occurrence.
-Duplicate item gradients are NOT pre-summed on the sender: every contribution carries its global key
-(i-part before j-part, then source rank, then batch position) and the owner sums them in ascending
-key order, i.e. exactly the order a single process sees for the concatenated global batch, so the
-tables are bit-identical at every world size.
+User rows never travel: a sample is processed by the rank that owns P[u].  Because the ids are replicated, every
+rank derives BOTH of its roles locally (`dr_route_views_i32`: what it processes and what it owns) -- which rows each
+peer will request from it, in which order the gradient rows of each peer arrive, and where each of them stands in
+the canonical order -- so no requests, counts or metadata are exchanged and a route needs one collective and one
+host synchronisation (the variable split sizes of the two row exchanges).
 
-Everything that depends on the ids only (bucketing, id exchanges, the owners' segment plans: `route`)
-is separated from what depends on table values (`run`), so a trainer routes batch t+1 on a second
-stream / second communicator while batch t runs (`ShardedBpr.step(..., next_batch=...)`); the two
-host synchronisations of a route (variable all-to-all split sizes) then wait on short id kernels only.
+The processing rank runs the lookup / dot / loss kernel on its own P shard and the fetched Q rows, updates its P
+rows locally, and ships one gradient row per item occurrence.  Duplicate item gradients are NOT pre-summed on the
+sender: the owner sums them in the order a single process sees for the concatenated global batch (i-part before
+j-part, then source rank, then batch position), so the tables are bit-identical at every world size.
+
+Everything that depends on the ids only (`route`) is separated from what depends on table values (`run`), so a
+trainer routes batch t+1 on a second stream / second communicator while batch t runs
+(`ShardedBpr.step(..., next_batch=...)`); the host synchronisation of a route then waits on short id kernels only.
 
 `ops` is the kernel namespace (default: deeprec_amd.kernels = the HIP library).  The package ships no
 other implementation; tests inject an oracle-backed namespace to exercise the exchange logic on CPU
@@ -30,15 +33,16 @@ with gloo.
 import torch
 import torch.distributed as dist
 
-POS_BITS = 24                    # batch position inside the source rank's batch
-RANK_BITS = 6                    # source rank (ranks of one node)
-PART_BIT = POS_BITS + RANK_BITS  # 0: positive item i, 1: negative item j  -> global keys have 31 bits
-
 
 def _a2a(out, inp, out_splits, in_splits, group, async_op=False):
-    """The one collective of this module (module-level so that a test can stage device tensors through the host
+    """The row exchange of this module (module-level so that a test can stage device tensors through the host
     when it runs several ranks on one GPU under gloo).  Returns the work handle when async_op, else None."""
     return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+
+
+def _gather_ids(out, inp, group):
+    """The id replication: out [W, 3, B] <- every rank's [3, B] (module-level for the same reason as _a2a)."""
+    dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group)
 
 
 class ShardedTable:
@@ -90,11 +94,12 @@ class BprRoute:
 class ShardedBpr:
     """BPR-MF training steps (bprmf.py:114-123) over row-sharded P and Q.
 
-    route(u, i, j) -> BprRoute      ids only: 5 collectives, 2 host syncs, the owners' segment plans
+    route(u, i, j) -> BprRoute      ids only: 1 collective (id all-gather), 1 host sync, the owners' segment plans
     run(route, opt) -> loss         table values: 2 collectives (rows in, gradient rows out), no host sync
     step(opt, next_batch)           run the prefetched route, then route next_batch on the side stream
 
-    group: communicator of the row / gradient exchanges; route_group: communicator of the id exchanges (created
+    Every rank passes a batch of the SAME length (the all-gather is fixed-size).
+    group: communicator of the row / gradient exchanges; route_group: communicator of the id all-gather (created
     here when the step is pipelined on GPUs, because the two run concurrently on different streams)."""
 
     def __init__(self, ops, P, Q, group=None, route_group=None, pipelined=None):
@@ -102,8 +107,8 @@ class ShardedBpr:
             raise ValueError("P and Q must be sharded over the same ranks and share k")
         self.ops, self.P, self.Q = ops, P, Q
         self.world, self.rank, self.group = P.world, P.rank, group
-        if self.world > (1 << RANK_BITS):
-            raise ValueError("at most %d ranks" % (1 << RANK_BITS))
+        if self.world > 64:
+            raise ValueError("at most 64 ranks")
         self.cuda = P.w.is_cuda
         self.pipelined = self.cuda if pipelined is None else bool(pipelined)
         self.collective = self.world > 1 or (dist.is_available() and dist.is_initialized())
@@ -113,7 +118,7 @@ class ShardedBpr:
         self.rpo = (Q.rows + self.world - 1) // self.world     # local rows per owner (upper bound)
         self.side = _side_stream(P.w.device) if (self.cuda and self.pipelined) else None
         self._pending = None
-        self._ev_done = None        # end of the previous run() on the main stream
+        self._retired = None
 
     # ---- exchanges -------------------------------------------------------------------------------------
     def _x(self, send, n_out, out_splits, in_splits, group, async_op=False):
@@ -124,44 +129,40 @@ class ShardedBpr:
         work = _a2a(out, send, out_splits, in_splits, group, async_op)
         return (out, work) if async_op else out
 
-    def _counts(self, counts, group):
-        """Exchange per-destination counts; returns (sent, received) as host lists: one host synchronisation."""
-        recv = self._x(counts, counts.shape[0], None, None, group)
-        sent, got = torch.stack((counts, recv)).tolist()
-        return sent, got
-
     # ---- ids only --------------------------------------------------------------------------------------
     def route(self, u, i, j):
-        ops, W, g = self.ops, self.world, self.route_group
+        ops, W = self.ops, self.world
         P, Q = self.P, self.Q
         B = u.numel()
-        if B >= (1 << POS_BITS):
-            raise ValueError("batch of %d samples per rank exceeds 2^%d" % (B, POS_BITS))
+        if i.numel() != B or j.numel() != B:
+            raise ValueError("u, i, j must have the same length")
+        if 4 * W * B >= (1 << 31) - 2:
+            raise ValueError("batch of %d samples per rank on %d ranks exceeds the 31-bit list index" % (B, W))
+        mine = torch.stack((u.reshape(-1), i.reshape(-1), j.reshape(-1))).to(torch.int32)
+        if self.collective:
+            ids = torch.empty((W, 3, B), dtype=torch.int32, device=mine.device)
+            _gather_ids(ids, mine, self.route_group)               # the one collective of a route
+        else:
+            ids = mine.reshape(1, 3, B)
+        rv = ops.route_views(ids, self.rank, P.rows, Q.rows, self.rpo)
+        c = rv.counts.tolist()                                     # the one host synchronisation of a route
+        # the ids are replicated, so every rank sees the same count: a bad batch on ONE rank is refused by ALL ranks
+        # here, before any of them enters a row exchange
+        if c[4 * W + 2]:
+            raise IndexError("sharded BPR step: %d samples of the global batch have a user / item id out of range"
+                             % c[4 * W + 2])
         rt = BprRoute()
-        # samples -> owners of their user rows
-        tup, cnt = ops.route_samples(u, i, j, W, P.rows, Q.rows, self.rank << POS_BITS)
-        # every peer gets (samples for it, this rank's count of samples with an id out of range): a bad batch on ONE
-        # rank is then refused by ALL ranks at the same point, instead of leaving the others in the next exchange
-        pair = torch.stack((cnt[:W], cnt[W:].expand(W)), 1).contiguous()
-        s1, r1 = self._counts(pair, g)                             # host sync 1
-        sc, rc = [c[0] for c in s1], [c[0] for c in r1]
-        n_bad = [c[1] for c in r1] if self.collective else [s1[0][1]]
-        if any(n_bad):
-            raise IndexError("sharded BPR step: samples with a user / item id out of range (per rank: %s)" % n_bad)
-        rt.n_s = n_s = int(sum(rc))
-        n_valid = int(sum(sc))
-        smp = self._x(tup[:n_valid], n_s, rc, sc, g)               # [n_s, 4] in (source rank, batch position) order
-        # item rows to fetch (distinct, per owner) and the contribution lists
-        ri = ops.route_items(smp, W, self.rpo, PART_BIT)
-        s2, r2 = self._counts(ri.counts, g)                        # host sync 2
-        rt.send_f, rt.recv_f = [c[0] for c in s2], [c[0] for c in r2]
-        rt.send_g, rt.recv_g = [c[1] for c in s2], [c[1] for c in r2]
-        rt.n_uq, rt.n_f, rt.n_g = int(sum(rt.send_f)), int(sum(rt.recv_f)), int(sum(rt.recv_g))
-        rt.rows_fetch = self._x(ri.uniq_rows[:rt.n_uq], rt.n_f, rt.recv_f, rt.send_f, g)
-        meta_r = self._x(ri.meta, rt.n_g, rt.recv_g, rt.send_g, g)
-        rt.ids_canon, rt.perm = ops.canon_contributions(meta_r, PART_BIT + 1)
-        rt.u_loc, rt.order_g = ri.u_loc, ri.order
-        rt.inv_i, rt.inv_j = ri.inv[:n_s], ri.inv[n_s:]
+        rt.send_f, rt.send_g = c[0:2 * W:2], c[1:2 * W:2]          # view 0, per owner: distinct rows, contributions
+        rt.recv_f, rt.recv_g = c[2 * W:4 * W:2], c[2 * W + 1:4 * W:2]    # view 1, per processing rank
+        n0, n1 = c[4 * W], c[4 * W + 1]
+        rt.n_s, rt.n_g = n0 // 2, n1
+        rt.n_uq, rt.n_f = sum(rt.send_f), sum(rt.recv_f)
+        n_s = rt.n_s
+        rt.u_loc = rv.u_loc[:n_s]
+        rt.inv_i, rt.inv_j = rv.inv[0, :n_s], rv.inv[0, n_s:2 * n_s]
+        rt.order_g = rv.order[0, :2 * n_s]
+        rt.rows_fetch = rv.uniq[1, :rt.n_f]
+        rt.ids_canon, rt.perm = rv.rows[1, :n1], rv.perm[1, :n1]
         # the owners' segment plans (namespaces without SegmentPlan -- the CPU oracle in tests -- plan in the update)
         rt.plan_p = rt.plan_q = None
         if hasattr(ops, "SegmentPlan"):
@@ -170,7 +171,7 @@ class ShardedBpr:
             if rt.n_g:
                 rt.plan_q = ops.SegmentPlan(rt.ids_canon, Q.w.shape[0], k_max=Q.k)
         rt.ready = None
-        rt.keep = (tup, smp, ri, meta_r)        # wire buffers: alive until the step that uses the route is enqueued
+        rt.keep = (ids, rv)                     # alive until the step that uses the route is enqueued
         return rt
 
     # ---- table values ----------------------------------------------------------------------------------
@@ -201,14 +202,17 @@ class ShardedBpr:
 
     # ---- one batch ahead -------------------------------------------------------------------------------
     def prefetch(self, u, i, j):
-        """Route a batch now (on the side stream when pipelined); step() consumes it."""
+        """Route a batch now (on the side stream when pipelined); step() consumes it.  The side stream first waits for
+        an event recorded HERE on the caller's current stream, so ids produced by earlier work on that stream are
+        complete before the route reads them -- and nothing enqueued on it later delays the route."""
         if self.side is None:
             self._pending = self.route(u, i, j)
             return
-        if self._ev_done is not None:
-            self.side.wait_event(self._ev_done)     # memory of routes retired before that point may be reused
-        else:
-            self.side.wait_stream(torch.cuda.current_stream())
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.side.wait_event(ready)
+        for t in (u, i, j):
+            t.record_stream(self.side)              # the caller may drop the batch right after step()
         with torch.cuda.stream(self.side):
             rt = self.route(u, i, j)
             rt.ready = torch.cuda.Event()
@@ -216,25 +220,22 @@ class ShardedBpr:
         self._pending = rt
 
     def step(self, opt, next_batch=None):
-        """Run the prefetched batch; then route `next_batch` = (u, i, j) while those kernels execute."""
+        """Run the prefetched batch; `next_batch` = (u, i, j) is routed meanwhile.  The route of next_batch is enqueued
+        BEFORE this batch's kernels: its side-stream work waits only for what the caller's stream held at that moment
+        (the previous step), so it overlaps this step's kernels, and its host synchronisation waits for id kernels only."""
         rt = self._pending
         if rt is None:
             raise RuntimeError("ShardedBpr.step: no routed batch (call prefetch first)")
         self._pending = None
+        if next_batch is not None:
+            self.prefetch(*next_batch)
         if rt.ready is not None:
             torch.cuda.current_stream().wait_event(rt.ready)
         loss = self.run(rt, opt)
-        if self.side is not None:
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream())
-            # prefetch() lets the side stream wait for the end of the PREVIOUS step only (so the route overlaps this
-            # step's kernels): side-stream memory it may reuse belongs to routes retired before that point, and this
-            # step's route (rt) stays referenced until the next one has been built
-            if next_batch is not None:
-                self.prefetch(*next_batch)
-            self._ev_done = done
-        elif next_batch is not None:
-            self.prefetch(*next_batch)
+        # side-stream memory of this route may be reused only by a route whose kernels wait for this run(): the next
+        # route to be enqueued does (its event is recorded after this point), the one enqueued above does not -- so
+        # the route stays referenced until the step after this one
+        self._retired = rt
         return loss
 
 

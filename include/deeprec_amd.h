@@ -417,31 +417,30 @@ int32_t dr_seq_dot_loss_f32(const float* W, const float* bias, int64_t num_item,
                             float scale, float* loss_b, float* gW, float* gb, float* gx, void* stream);
 
 /* ---- row-sharded BPR step: routing helpers (no counterpart in the reference; SURVEY 8e, deeprec_amd/sharding.py) ----
- * A sample (u, i, j) of rank r's batch is processed by the rank that owns P[u] (u % world); that rank fetches the
- * distinct Q rows its samples need from their owners (row % world), and sends the item-side gradient rows back.
- * Every function is a handful of short kernels around one rocPRIM radix sort; outputs are pure functions of the
- * inputs (restated in tests/_oracle_ops.py).  ws: dr_route_bytes(number of sorted keys), 256-byte aligned.
+ * A sample (u, i, j) is processed by the rank that owns P[u] (u % world); that rank fetches the distinct Q rows its
+ * samples need from their owners (row % world) and sends the item-side gradient rows back.  The id lists of all ranks
+ * are REPLICATED (one fixed-size all-gather), so each rank derives both of its roles locally and no requests, counts or
+ * metadata travel.  ws: dr_route_bytes(number of sorted keys), 256-byte aligned.
  *
- * dr_route_samples_i32: tuples[y] = (u / world, i, j, tag + position) of the batch's samples bucketed by u % world,
- * batch order inside a bucket (stable); counts[r] = samples for rank r, counts[world] = samples with an id out of
- * range (packed last; the caller rejects the batch).  Sorted keys: B.
- * dr_route_items_i32: `samples` = the n tuples a rank received.  List entry e < n is item i of sample e, entry
- * n + e item j.  Sorted by (owner, local row, e): order[y] = e; meta[y] = (local row at the owner, global key =
- * tuple tag | (e >= n) << part_bit) -- the wire order of the gradient contributions; uniq_rows[s] = local row of the
- * s-th distinct item (the wire order of the row requests); inv[e] = s; u_loc[e] = tuple user row;
- * counts[2r] = distinct items owned by rank r, counts[2r+1] = list entries owned by rank r.  Sorted keys: 2n.
- * dr_canon_contributions_i32: received (row, global key) pairs -> perm = their order by ascending global key (the
- * order a single process sees for the concatenated global batch), ids_canon[y] = row of pair perm[y].  Sorted keys: n.
+ * dr_route_views_i32: ids = [world][3][B] int32, rank s's (u, i, j) lists; global sample g = s * B + position; list
+ * entry e in [0, 2 world B): part = e / (world B) (0: item i, 1: item j) of sample e % (world B) -- ascending e is the
+ * order a single process sees for the concatenated global batch (the canonical contribution order).
+ *   view 0 (this rank processes): entries of samples with u % world == me, sorted by (owner of the item, local row, e)
+ *   view 1 (this rank owns):      entries with item % world == me,         sorted by (u % world,         local row, e)
+ * Per view v, written at offset v * 2 world B of every output: c = index of the entry among the view's entries in
+ * ascending e, y = its position in the sorted order, s = index of its distinct (major, row):
+ *   rows[c] = local row at the owner, inv[c] = s, order[y] = c, perm[c] = y, uniq[s] = row;
+ *   u_loc[c] = u / world for the view-0 entries of part 0 (c < samples processed here).
+ * counts (int64 [4 world + 3]): [2 (v world + m)] distinct rows, [.. + 1] entries of major m (view 0: owner rank, view 1:
+ * processing rank); [4 world + v] entries of view v; [4 world + 2] samples of the GLOBAL batch with an id out of range
+ * (they belong to no view; every rank computes the same number and refuses the batch).  Sorted keys: 4 world B + 1.
+ * Sender and receiver of every exchange derive the same order: view 0 of rank r restricted to owner o lists the same
+ * (row, e) sequence as view 1 of rank o restricted to processing rank r.
  * dr_bpr_item_grads_f32: out[y] = c * P[u_loc[s]] with e = order[y], s = e mod n, c = +g[s] (e < n) or -g[s]. */
 int64_t dr_route_bytes(int64_t n_keys);
-int32_t dr_route_samples_i32(const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, int32_t world,
-                             int64_t num_user, int64_t num_item, int32_t tag, int32_t* tuples, int64_t* counts,
-                             void* ws, int64_t ws_bytes, void* stream);
-int32_t dr_route_items_i32(const int32_t* samples, int64_t n, int32_t world, int64_t rows_per_owner, int32_t part_bit,
-                           int32_t* u_loc, int32_t* inv, int32_t* uniq_rows, int32_t* meta, int32_t* order,
-                           int64_t* counts, void* ws, int64_t ws_bytes, void* stream);
-int32_t dr_canon_contributions_i32(const int32_t* meta, int64_t n, int32_t key_bits, int32_t* ids_canon, int32_t* perm,
-                                   void* ws, int64_t ws_bytes, void* stream);
+int32_t dr_route_views_i32(const int32_t* ids, int32_t world, int64_t B, int32_t me, int64_t num_user, int64_t num_item,
+                           int64_t rows_per_owner, int32_t* u_loc, int32_t* rows, int32_t* inv, int32_t* order,
+                           int32_t* perm, int32_t* uniq, int64_t* counts, void* ws, int64_t ws_bytes, void* stream);
 int32_t dr_bpr_item_grads_f32(const float* P, int64_t rows, int32_t k, const int32_t* u_loc, const float* g,
                               const int32_t* order, int64_t n, float* out, void* stream);
 

@@ -24,53 +24,56 @@ def bucket_order(keys, nkeys):
     return torch.from_numpy(order), torch.from_numpy(np.bincount(kk, minlength=nkeys).astype(np.int64))
 
 
-def route_samples(u, i, j, world, num_user, num_item, tag):
-    """numpy restatement of dr_route_samples_i32 (include/deeprec_amd.h)."""
-    u, i, j = (_n(x).astype(np.int64) for x in (u, i, j))
-    bad = (u < 0) | (u >= num_user) | (i < 0) | (i >= num_item) | (j < 0) | (j >= num_item)
-    key = np.where(bad, world, u % world)
-    order = np.argsort(key, kind="stable")
-    tup = np.stack((u // world, i, j, tag + np.arange(len(u))), 1)[order].astype(np.int32)
-    return torch.from_numpy(tup.reshape(-1, 4)), torch.from_numpy(np.bincount(key, minlength=world + 1).astype(np.int64))
-
-
-class ItemRoute:
+class RouteViews:
     pass
 
 
-def route_items(samples, world, rows_per_owner, part_bit):
-    """numpy restatement of dr_route_items_i32."""
-    smp = _n(samples).astype(np.int64).reshape(-1, 4)
-    n = smp.shape[0]
-    ids = np.concatenate((smp[:, 1], smp[:, 2]))
-    gkey = np.concatenate((smp[:, 3], smp[:, 3] | (1 << part_bit)))
-    okey = (ids % world) * rows_per_owner + ids // world
-    order = np.argsort(okey, kind="stable")
-    sk = okey[order]
-    head = np.ones(2 * n, dtype=bool)
-    head[1:] = sk[1:] != sk[:-1]
-    seg = np.cumsum(head) - 1
-    inv = np.empty(2 * n, dtype=np.int32)
-    inv[order] = seg
-    uniq = sk[head]
-    r = ItemRoute()
-    r.u_loc = torch.from_numpy(smp[:, 0].astype(np.int32))
-    r.inv = torch.from_numpy(inv)
-    ur = np.zeros(2 * n, dtype=np.int32)
-    ur[:len(uniq)] = uniq % rows_per_owner
-    r.uniq_rows = torch.from_numpy(ur)
-    r.meta = torch.from_numpy(np.stack((sk % rows_per_owner, gkey[order]), 1).astype(np.int32).reshape(-1, 2))
-    r.order = torch.from_numpy(order.astype(np.int32))
-    r.counts = torch.from_numpy(np.stack((np.bincount(uniq // rows_per_owner, minlength=world),
-                                          np.bincount(ids % world, minlength=world)), 1).astype(np.int64))
+def route_views(ids, me, num_user, num_item, rows_per_owner):
+    """numpy restatement of dr_route_views_i32 (include/deeprec_amd.h): both roles of rank `me` from the replicated
+    id lists [world, 3, B].  Unused tails of the outputs are zero here (unspecified in the library)."""
+    g = _n(ids).astype(np.int64)
+    W, _, B = g.shape
+    WB = W * B
+    u, i, j = g[:, 0, :].reshape(-1), g[:, 1, :].reshape(-1), g[:, 2, :].reshape(-1)
+    ok = (u >= 0) & (u < num_user) & (i >= 0) & (i < num_item) & (j >= 0) & (j < num_item)
+    item = np.concatenate((i, j))                    # list entry e: part = e // WB, sample e % WB
+    uu = np.concatenate((u, u))
+    ok2 = np.concatenate((ok, ok))
+    r = RouteViews()
+    n = 2 * WB
+    r.n_list = n
+    out = {name: np.zeros((2, max(n, 1)), np.int32) for name in ("rows", "inv", "order", "perm", "uniq")}
+    u_loc = np.zeros(max(WB, 1), np.int32)
+    counts = np.zeros(4 * W + 3, np.int64)
+    for v in range(2):
+        mine = ok2 & ((item % W == me) if v else (uu % W == me))
+        e = np.nonzero(mine)[0]                      # ascending e = canonical order; c = index into e
+        major = (uu[e] % W) if v else (item[e] % W)
+        row = item[e] // W
+        key = major * rows_per_owner + row
+        order = np.argsort(key, kind="stable")       # y -> c
+        sk = key[order]
+        head = np.ones(len(e), dtype=bool)
+        head[1:] = sk[1:] != sk[:-1]
+        seg = np.cumsum(head) - 1
+        m = len(e)
+        out["rows"][v, :m] = row
+        out["order"][v, :m] = order
+        out["perm"][v, order] = np.arange(m)
+        out["inv"][v, order] = seg
+        out["uniq"][v, :int(head.sum())] = sk[head] % rows_per_owner
+        counts[2 * v * W:2 * (v + 1) * W:2] = np.bincount(sk[head] // rows_per_owner, minlength=W)
+        counts[2 * v * W + 1:2 * (v + 1) * W:2] = np.bincount(major, minlength=W)
+        counts[4 * W + v] = m
+        if v == 0:
+            first = e[e < WB]
+            u_loc[:len(first)] = u[first] // W
+    counts[4 * W + 2] = int((~ok).sum())
+    for name, a in out.items():
+        setattr(r, name, torch.from_numpy(a))
+    r.u_loc = torch.from_numpy(u_loc)
+    r.counts = torch.from_numpy(counts)
     return r
-
-
-def canon_contributions(meta, key_bits):
-    """numpy restatement of dr_canon_contributions_i32."""
-    m = _n(meta).reshape(-1, 2)
-    perm = np.argsort(m[:, 1], kind="stable").astype(np.int32)
-    return torch.from_numpy(m[perm, 0].astype(np.int32)), torch.from_numpy(perm)
 
 
 def bpr_item_grads(P, u_loc, g, order):

@@ -1,7 +1,7 @@
 """GPU tests of the row-sharded BPR step (deeprec_amd/sharding.py) on the real HIP kernels:
 
-* the routing entry points (dr_route_samples_i32, dr_route_items_i32, dr_canon_contributions_i32,
-  dr_bpr_item_grads_f32) against their numpy restatements in tests/_oracle_ops.py, bit for bit;
+* the routing entry points (dr_route_views_i32, dr_bpr_item_grads_f32) against their numpy restatements in
+  tests/_oracle_ops.py, bit for bit;
 * one rank through RCCL (process group of size 1, pipelined trainer with its second communicator and stream);
 * two ranks sharing the one GPU of the box (gloo, device tensors staged through the host for the exchanges --
   RCCL refuses two ranks on one device), pipelined: tables bit-identical to the fused single-GPU step on the
@@ -39,46 +39,49 @@ def _free_port():
 
 
 # ------------------------------------------------------------------ routing kernels vs numpy restatement
-@pytest.mark.parametrize("B,W", [(1, 1), (1000, 1), (4096, 2), (70001, 8), (5000, 3)])
-def test_route_samples(dev, B, W):
+@pytest.mark.parametrize("B,W,ni", [(1, 1, 10), (1000, 1, 701), (4096, 2, 700), (20001, 8, 100000), (5000, 3, 17),
+                                    (300, 5, 3)])
+def test_route_views(dev, B, W, ni):
+    """dr_route_views_i32 for every rank of the world against the numpy restatement, bit for bit; and the property the
+    exchanges rest on: what rank r's processing view sends to owner o is, entry for entry, what o's owner view expects
+    from r."""
     from deeprec_amd import kernels as K
     import _oracle_ops as O
     rng = np.random.default_rng(B + W)
-    nu, ni = 100003, 5003
-    u = rng.integers(0, nu, B).astype(np.int32)
-    i = rng.integers(0, ni, B).astype(np.int32)
-    j = rng.integers(0, ni, B).astype(np.int32)
-    if B > 10:
-        u[3], i[5], j[7] = -1, ni, -5                 # invalid samples sort last and are counted apart
-    tag = 5 << 24
-    tup, cnt = K.route_samples(T(u, dev), T(i, dev), T(j, dev), W, nu, ni, tag)
-    wt, wc = O.route_samples(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(j), W, nu, ni, tag)
-    nv = int(wc[:W].sum())
-    assert np.array_equal(N(cnt), wc.numpy())
-    assert np.array_equal(N(tup)[:nv], wt.numpy()[:nv])
-
-
-@pytest.mark.parametrize("n,W,ni", [(1, 1, 10), (3000, 1, 701), (4096, 2, 700), (60000, 8, 100000), (5000, 3, 17)])
-def test_route_items_and_canon(dev, n, W, ni):
-    from deeprec_amd import kernels as K
-    from deeprec_amd import sharding as sh
-    import _oracle_ops as O
-    rng = np.random.default_rng(n + W)
+    nu = 100003
     rpo = (ni + W - 1) // W
-    smp = np.stack((rng.integers(0, 1000, n), rng.zipf(1.2, n) % ni, rng.integers(0, ni, n),
-                    rng.permutation(n) + (3 << sh.POS_BITS)), 1).astype(np.int32)
-    got = K.route_items(T(smp, dev), W, rpo, sh.PART_BIT)
-    want = O.route_items(torch.from_numpy(smp), W, rpo, sh.PART_BIT)
-    nuq = int(want.counts[:, 0].sum())
-    assert np.array_equal(N(got.counts), want.counts.numpy())
-    for name in ("u_loc", "inv", "meta", "order"):
-        assert np.array_equal(N(getattr(got, name)), getattr(want, name).numpy()), name
-    assert np.array_equal(N(got.uniq_rows)[:nuq], want.uniq_rows.numpy()[:nuq])
-    # owner side: any interleaving of such lists is brought back to ascending global key
-    meta = want.meta.numpy()[rng.permutation(2 * n)]
-    ids, perm = K.canon_contributions(T(meta, dev), sh.PART_BIT + 1)
-    wi, wp = O.canon_contributions(torch.from_numpy(meta), sh.PART_BIT + 1)
-    assert np.array_equal(N(ids), wi.numpy()) and np.array_equal(N(perm), wp.numpy())
+    ids = np.stack((rng.integers(0, nu, (W, B)), rng.zipf(1.2, (W, B)) % ni, rng.integers(0, ni, (W, B))), 1).astype(np.int32)
+    if B > 10:
+        ids[0, 0, 3], ids[W - 1, 1, 5], ids[0, 2, 7] = -1, ni, -5      # invalid samples belong to no view, counted apart
+    views = []
+    for me in range(W):
+        got = K.route_views(T(ids, dev), me, nu, ni, rpo)
+        want = O.route_views(torch.from_numpy(ids), me, nu, ni, rpo)
+        c = want.counts.numpy()
+        assert np.array_equal(N(got.counts), c), me
+        assert c[4 * W + 2] == (3 if B > 10 else 0)
+        for v in range(2):
+            m = int(c[4 * W + v])
+            nseg = int(c[2 * v * W:2 * (v + 1) * W:2].sum())
+            for name in ("rows", "inv", "order", "perm"):
+                assert np.array_equal(N(getattr(got, name))[v, :m], getattr(want, name).numpy()[v, :m]), (me, v, name)
+            assert np.array_equal(N(got.uniq)[v, :nseg], want.uniq.numpy()[v, :nseg]), (me, v)
+        n_s = int(c[4 * W]) // 2
+        assert np.array_equal(N(got.u_loc)[:n_s], want.u_loc.numpy()[:n_s])
+        views.append((want, c))
+    # sender / receiver agreement, from the restatement's outputs: rows in wire order
+    for r in range(W):
+        vr, cr = views[r]
+        wire_r = vr.rows.numpy()[0][vr.order.numpy()[0, :int(cr[4 * W])]]              # rows of r's contributions, sorted
+        so = np.concatenate(([0], np.cumsum(cr[1:2 * W:2])))
+        fo = np.concatenate(([0], np.cumsum(cr[0:2 * W:2])))
+        for o in range(W):
+            vo, co = views[o]
+            wire_o = vo.rows.numpy()[1][vo.order.numpy()[1, :int(co[4 * W + 1])]]
+            ro_ = np.concatenate(([0], np.cumsum(co[2 * W + 1:4 * W:2])))
+            fr = np.concatenate(([0], np.cumsum(co[2 * W:4 * W:2])))
+            assert np.array_equal(wire_r[so[o]:so[o + 1]], wire_o[ro_[r]:ro_[r + 1]]), (r, o)
+            assert np.array_equal(vr.uniq.numpy()[0, fo[o]:fo[o + 1]], vo.uniq.numpy()[1, fr[r]:fr[r + 1]]), (r, o)
 
 
 @pytest.mark.parametrize("k", [1, 10, 30, 64, 128, 150])
@@ -193,7 +196,13 @@ def _stage_through_host(sh, dist):
                 return True
         return Done() if async_op else None
 
+    def gather_staged(o, inp, group):
+        oc = torch.empty(o.shape, dtype=o.dtype)
+        dist.all_gather_into_tensor(oc.view(-1), inp.cpu().view(-1), group=group)
+        o.copy_(oc)
+
     sh._a2a = staged
+    sh._gather_ids = gather_staged
 
 
 def _worker2(rank, world, port, out):

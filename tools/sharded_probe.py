@@ -70,21 +70,20 @@ def main():
     print("run():   host %.3f ms, host+GPU %.3f ms" % (h, g))
     # pieces of route()
     u, i, j = batches[0]
-    h, g = timed(lambda: K.route_samples(u, i, j, 1, args.users, args.items, 0), a.steps)
-    print("  route_samples: host %.3f, total %.3f" % (h, g))
-    tup, _ = K.route_samples(u, i, j, 1, args.users, args.items, 0)
-    h, g = timed(lambda: K.route_items(tup, 1, args.items, sh.PART_BIT), a.steps)
-    print("  route_items:   host %.3f, total %.3f" % (h, g))
-    ri = K.route_items(tup, 1, args.items, sh.PART_BIT)
-    h, g = timed(lambda: K.canon_contributions(ri.meta, sh.PART_BIT + 1), a.steps)
-    print("  canon:         host %.3f, total %.3f" % (h, g))
+    ids = torch.stack((u, i, j)).reshape(1, 3, -1)
+    h, g = timed(lambda: K.route_views(ids, 0, args.users, args.items, args.items), a.steps)
+    print("  route_views:   host %.3f, total %.3f" % (h, g))
+    rv = K.route_views(ids, 0, args.users, args.items, args.items)
+    h, g = timed(lambda: rv.counts.tolist(), a.steps)
+    print("  counts sync:   host %.3f, total %.3f" % (h, g))
+    if a.rccl:
+        out = torch.empty_like(ids)
+        h, g = timed(lambda: sh._gather_ids(out, ids[0], None), a.steps)
+        print("  id all-gather through RCCL (self): host %.3f, total %.3f" % (h, g))
     h, g = timed(lambda: K.SegmentPlan(rt.ids_canon, args.items, k_max=args.k), a.steps)
     print("  plan_q:        host %.3f, total %.3f" % (h, g))
     h, g = timed(lambda: K.SegmentPlan(rt.u_loc, args.users, k_max=args.k), a.steps)
     print("  plan_p:        host %.3f, total %.3f" % (h, g))
-    cc = ri.counts
-    h, g = timed(lambda: tr._counts(cc, None), a.steps)
-    print("  counts+sync:   host %.3f, total %.3f" % (h, g))
     # pieces of run()
     h, g = timed(lambda: K.gather(Qt.w, rt.rows_fetch), a.steps)
     print("  gather Q rows (%d distinct of %d): host %.3f, total %.3f" % (rt.n_uq, 2 * rt.n_s, h, g))
