@@ -99,6 +99,131 @@ __global__ __launch_bounds__(256) void hconv_pool_fwd_kernel(const float* __rest
     }
 }
 
+// ---- direct forward: no G --------------------------------------------------------------------------------------
+// out[b, h, c] = max(0, max_t (bias + sum_{r < h} <e[b, t + r], W[h, c, r]>)) computed where it is needed only:
+// L (L + 1) (L + 2) / 6 row products per (sequence, filter) instead of the L^2 (L + 1) / 2 of G = e W^T (2.9x fewer at
+// L = 50), and nothing round-trips through HBM.  v_mfma_f32_16x16x4_f32 with M = 16 SEQUENCES (so every MFMA row is
+// useful whatever L - h + 1 is), N = 16 filters of one height, K = the window's h d elements.  One wave owns
+// (height h, 16 sequences) and walks the positions in blocks of 8: 8 accumulators; per (row r, 16-column block) ONE
+// new 16-byte operand load per lane for each of e and W feeds 32 MFMAs, because the windows of 8 consecutive
+// positions share all but one slab row per r.  Operands come straight from L2 (W: 10 MB at C5, e: 25 KB per
+// sequence); the four waves of a workgroup share h, so W's rows are in the CU's vector L1 for three of them.
+// Lane l: i = l % 16 (sequence as A row / filter as B column), q = l / 16; its float4 holds columns 16 cb + 4 q + j,
+// and MFMA j contracts over q.  D: lane holds (sequence 4 q + v, filter i), v = 0..3.
+typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int hc_height_of_rank(int rank, int L) {   // descending cost h (L + 1 - h): middle outwards
+    const int mid = (L + 1) / 2;
+    return (rank & 1) ? mid + (rank + 1) / 2 : mid - rank / 2;
+}
+
+#define HC_LD4(p) (*reinterpret_cast<const hc_f32x4*>(p))
+
+// TT positions t0 .. t0 + TT - 1 of height h for the wave's 16 sequences x 16 filters: best / bt updated.
+// Rows r are taken in groups of 8: the group's 8 filter rows (bcur) and the 8 + 8 slab rows t0 + r0 .. t0 + r0 + 15 its
+// windows touch (a, anew) are in registers, the NEXT group's operands are requested before the group's 32 TT MFMAs.
+template <int TT>
+__device__ __forceinline__ void hc_block(const float* __restrict__ ea, const float* __restrict__ wb, int d, int ncb, int L,
+                                         int h, int t0, float bv, float (&best)[4], int (&bt)[4]) {
+    hc_f32x4 acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[tt] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int cb = 0; cb < ncb; ++cb) {
+        const float* ec = ea + cb * 16;
+        const float* wc = wb + cb * 16;
+        hc_f32x4 a[8], bcur[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = (t0 + k < L) ? t0 + k : L - 1;          // rows / filter rows past the end: clamped, unused
+            a[k] = HC_LD4(ec + (int64_t)row * d);
+            bcur[k] = HC_LD4(wc + (int64_t)(k < h ? k : h - 1) * d);
+        }
+        for (int r0 = 0; r0 < h; r0 += 8) {
+            const int nr = h - r0;
+            hc_f32x4 anew[8], bnext[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = (t0 + r0 + 8 + k < L) ? t0 + r0 + 8 + k : L - 1;
+                anew[k] = HC_LD4(ec + (int64_t)row * d);
+                bnext[k] = HC_LD4(wc + (int64_t)(r0 + 8 + k < h ? r0 + 8 + k : h - 1) * d);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u < nr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) {
+                            const float av = (u + tt < 8) ? a[(u + tt) & 7][j] : anew[(u + tt) & 7][j];
+                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcur[u][j], acc[tt], 0, 0, 0);
+                        }
+                }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] = anew[k];
+                bcur[k] = bnext[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float val = acc[tt][v] + bv;
+            if (val > best[v]) {
+                best[v] = val;
+                bt[v] = t0 + tt;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void hconv_direct_fwd_kernel(const float* __restrict__ e, const float* __restrict__ W,
+                                                                  const float* __restrict__ bias, int64_t B, int L, int C,
+                                                                  int d, int nsg, float* __restrict__ out,
+                                                                  int32_t* __restrict__ arg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int h = hc_height_of_rank(blockIdx.x / nsg, L);
+    const int64_t s0 = ((int64_t)(blockIdx.x % nsg) * 4 + wave) * 16;
+    if (s0 >= B) return;
+    const int T = L - h + 1, ncb = d / 16;
+    const int64_t seq = (s0 + i < B) ? s0 + i : B - 1;
+    const int filt = i < C ? i : C - 1;
+    const float* ea = e + seq * L * d + 4 * q;
+    const float* wb = W + (hc_off(C, h) + (int64_t)filt * h) * d + 4 * q;
+    const float bv = bias[(h - 1) * C + filt];
+    float best[4];
+    int bt[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        best[v] = -INFINITY;
+        bt[v] = 0;
+    }
+    int t0 = 0;
+    for (; t0 + 8 <= T; t0 += 8) hc_block<8>(ea, wb, d, ncb, L, h, t0, bv, best, bt);
+    switch (T - t0) {
+        case 1: hc_block<1>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
+        case 2: hc_block<2>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
+        case 3: hc_block<3>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
+        case 4: hc_block<4>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
+        case 5: hc_block<5>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
+        case 6: hc_block<6>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
+        case 7: hc_block<7>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
+        default: break;
+    }
+    if (i < C) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t sq = s0 + 4 * q + v;
+            if (sq < B) {
+                const int64_t o = sq * ((int64_t)C * L) + (h - 1) * C + i;
+                out[o] = best[v] > 0.0f ? best[v] : 0.0f;
+                arg[o] = best[v] > 0.0f ? bt[v] : -1;
+            }
+        }
+    }
+}
+
 // d e: one workgroup per sequence accumulates its [L, d] tile in LDS; columns V (tid % LPR) .. +V-1 of row p belong to
 // one thread (p % (256 / LPR) = tid / LPR), contributions added in ascending (h, c, r)
 template <int V, int LPR>
@@ -241,6 +366,22 @@ extern "C" int32_t dr_caser_hconv_pool_f32(const float* G, int64_t ldg, const fl
     DR_LAUNCH_NAMED("hconv_pool_fwd_kernel", hconv_pool_fwd_kernel, dim3(nbands, gy), dim3(256), lds,
                     (hipStream_t)stream, G, ldg, bias, B, (int)L, (int)C, (int)h0, (int)h1, out, arg);
     DR_CHECK_LAUNCH("hconv_pool_fwd_kernel");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_caser_hconv_direct_f32(const float* e, const float* W, const float* bias, int64_t B, int32_t L,
+                                             int32_t C, int32_t d, float* out, int32_t* arg, void* stream) {
+    if (int rc = hc_check("dr_caser_hconv_direct_f32", B, L, C, d)) return rc;
+    DR_REQUIRE(C <= 16 && d % 16 == 0, "dr_caser_hconv_direct_f32: needs C <= 16 filters per height and d %% 16 == 0 (got C=%d d=%d)",
+               C, d);
+    if (B == 0) return DR_OK;
+    DR_REQUIRE(e && W && bias && out && arg && (((uintptr_t)e | (uintptr_t)W) % 16 == 0),
+               "dr_caser_hconv_direct_f32: NULL / misaligned pointer");
+    const int64_t nsg = (B + 63) / 64;
+    DR_REQUIRE(nsg * L < (1ll << 31) - 1, "dr_caser_hconv_direct_f32: grid too large");
+    DR_LAUNCH_NAMED("hconv_direct_fwd_kernel", hconv_direct_fwd_kernel, dim3((unsigned)(nsg * L)), dim3(256), 0,
+                    (hipStream_t)stream, e, W, bias, B, (int)L, (int)C, (int)d, (int)nsg, out, arg);
+    DR_CHECK_LAUNCH("hconv_direct_fwd_kernel");
     return DR_OK;
 }
 

@@ -618,19 +618,28 @@ def hconv_rows(C, h):
     return C * h * (h - 1) // 2
 
 
-def caser_hconv_forward(e, W, bias, C, chunk_cols=None):
+def caser_hconv_forward(e, W, bias, C, chunk_cols=None, direct=None):
     """Caser.py:132-154: e [B, L, d], W [C L (L+1) / 2, d], bias [C L] -> (out [B, C L], arg int32 [B, C L]).
-    The products G = e W^T are library GEMMs over column chunks of whole heights (<= chunk_cols columns each)."""
+    direct (default: whenever the shape allows, C <= 16 and d % 16 == 0): dr_caser_hconv_direct_f32, the windowed products
+    on MFMA straight from e and W.  Otherwise the products G = e W^T are library GEMMs over column chunks of whole
+    heights (<= chunk_cols columns each) followed by dr_caser_hconv_pool_f32."""
     e = _req(e, torch.float32, "e", 3)
     W = _req(W, torch.float32, "W", 2)
     bias = _req(bias, torch.float32, "bias", 1)
     B, L, d = e.shape
     if W.shape != (hconv_rows(C, L + 1), d) or bias.numel() != C * L:
         raise ValueError("caser_hconv_forward: W must be [C L (L+1) / 2, d] and bias [C L]")
-    if chunk_cols is None:
-        chunk_cols = HCONV_CHUNK_COLS
     out = torch.empty((B, C * L), dtype=torch.float32, device=e.device)
     arg = torch.empty((B, C * L), dtype=torch.int32, device=e.device)
+    can = C <= 16 and d % 16 == 0 and L <= HC_MAX_L and d <= HC_MAX_D
+    if direct is None:
+        direct = can and chunk_cols is None
+    if chunk_cols is None:
+        chunk_cols = HCONV_CHUNK_COLS
+    if direct:
+        check(_abi.lib().dr_caser_hconv_direct_f32(_ptr(e), _ptr(W), _ptr(bias), B, L, C, d, _ptr(out), _ptr(arg),
+                                                   _stream()), "dr_caser_hconv_direct_f32")
+        return out, arg
     e2 = e.reshape(B * L, d)
     h0 = 1
     while h0 <= L:

@@ -381,6 +381,9 @@ int32_t dr_attn_pool_backward_f32(const float* pre, const float* v, const float*
  * dr_caser_hconv_pool_f32: G [B L, ldg] = e W[rows of heights h0 .. h1]^T (a library GEMM; column 0 = row
  * C h0 (h0 - 1) / 2 of W) -> out / arg for those heights: out = max(0, max_t (sum_r G[b, t + r, (h, c, r)] + bias)),
  * arg = the winning position t, or -1 where the ReLU is inactive.
+ * dr_caser_hconv_direct_f32: the same out / arg for ALL heights straight from e and W (no G): only the L (L+1) (L+2) / 6
+ * (row, filter row) products per filter that some window uses, on v_mfma_f32_16x16x4_f32 with 16 sequences as the M
+ * dimension.  Needs C <= 16 and d % 16 == 0 (DR_ERR_ARG otherwise: use the pooling form).
  * dr_caser_hconv_backward_input_f32: gout [B, C L] = dLoss/dout, arg -> ge [B, L, d] (overwritten):
  * ge[b, arg + r] += gout[b, (h, c)] W[(h, c, r)], summed in ascending (h, c, r).
  * dr_caser_hconv_backward_filter_f32: -> partial [S, C L (L + 1) / 2, d]: the filter gradient of batch chunk s (S
@@ -388,6 +391,8 @@ int32_t dr_attn_pool_backward_f32(const float* pre, const float* v, const float*
  * column sum of gout where arg >= 0.  1 <= L <= 64, 1 <= C <= 64, 1 <= d <= 256, 1 <= S <= 64. */
 int32_t dr_caser_hconv_pool_f32(const float* G, int64_t ldg, const float* bias, int64_t B, int32_t L, int32_t C,
                                 int32_t h0, int32_t h1, float* out, int32_t* arg, void* stream);
+int32_t dr_caser_hconv_direct_f32(const float* e, const float* W, const float* bias, int64_t B, int32_t L, int32_t C,
+                                  int32_t d, float* out, int32_t* arg, void* stream);
 int32_t dr_caser_hconv_backward_input_f32(const float* gout, const int32_t* arg, const float* W, int64_t B, int32_t L,
                                           int32_t C, int32_t d, float* ge, void* stream);
 int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const int32_t* arg, const float* e, int64_t B, int32_t L,

@@ -899,7 +899,8 @@ def test_attn_pool_rejects_bad_shapes(dev):
 
 
 # ------------------------------------------------------------------ Caser horizontal convolutions
-@pytest.mark.parametrize("B,L,d,C", [(5, 5, 16, 4), (300, 7, 30, 3), (600, 50, 128, 16), (3, 64, 256, 2), (2, 1, 8, 1)])
+@pytest.mark.parametrize("B,L,d,C", [(5, 5, 16, 4), (300, 7, 30, 3), (600, 50, 128, 16), (3, 64, 256, 2), (2, 1, 8, 1),
+                                     (77, 19, 32, 16), (130, 9, 48, 5)])
 def test_caser_hconv_forward_backward(dev, B, L, d, C):
     """dr_caser_hconv_pool_f32 / _backward_input_f32 / _backward_filter_f32 (Caser.py:132-154): pooled output and winning
     positions against the oracle's literal convolution, gradients against float64 autograd through the library form
@@ -941,8 +942,19 @@ def test_caser_hconv_forward_backward(dev, B, L, d, C):
     for a, b_ in ((out, out2), (arg, arg2), (ge, ge2), (gW, gW2), (gb, gb2)):
         assert torch.equal(a, b_)
     # default chunking: the library GEMM runs other shapes (its summation order may differ), same result within rounding
-    out3, _ = K.caser_hconv_forward(te, tW, tb, C)
+    out3, _ = K.caser_hconv_forward(te, tW, tb, C, direct=False)
     np.testing.assert_allclose(N(out3), o_out, rtol=1e-5, atol=1e-5 * scale)
+    if C <= 16 and d % 16 == 0:
+        # dr_caser_hconv_direct_f32 (no G; MFMA over 16 sequences x 16 filters): same contract, checked against the oracle
+        out4, arg4 = K.caser_hconv_forward(te, tW, tb, C, direct=True)
+        np.testing.assert_allclose(N(out4), o_out, rtol=1e-5, atol=1e-5 * scale)
+        assert np.array_equal(N(arg4)[clear] >= 0, o_arg[clear] >= 0)
+        assert (N(arg4) == o_arg).mean() > 0.999
+        out5, arg5 = K.caser_hconv_forward(te, tW, tb, C, direct=True)
+        assert torch.equal(out4, out5) and torch.equal(arg4, arg5)
+    else:
+        with pytest.raises(Exception, match="needs C <= 16"):
+            K.caser_hconv_forward(te, tW, tb, C, direct=True)
 
 
 def test_caser_hconv_empty_batch_and_limits(dev):
