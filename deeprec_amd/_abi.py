@@ -78,6 +78,8 @@ SIGNATURES = {
     "dr_mlp_backward_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "dr_attn_pool_forward_f32": (_i32, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "dr_attn_pool_backward_f32": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "dr_caser_vconv_forward_f32": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),
+    "dr_caser_vconv_backward_f32": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "dr_caser_hconv_direct_f32": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p]),
     "dr_caser_hconv_pool_f32": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "dr_caser_hconv_backward_input_f32": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),

@@ -332,6 +332,85 @@ __global__ __launch_bounds__(256) void hconv_bwd_filter_kernel(const float* __re
     }
 }
 
+// ---- vertical convolution (Caser.py:118-130): out[b, col * n_v + v] = bias[v] + sum_l w[v, l] e[b, l, col] -------------
+// One thread per (sequence, column): the L slab elements of its column are read once (coalesced over the columns), the
+// n_v filters sit in LDS.  HBM / L2 bound on the slab (B L d floats); no MFMA: n_v = 4 outputs per L = 50 inputs.
+constexpr int VC_MAX_NV = 16;
+
+__global__ __launch_bounds__(256) void vconv_fwd_kernel(const float* __restrict__ e, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int64_t B, int L, int d, int nv,
+                                                        float* __restrict__ out) {
+    __shared__ float ws[VC_MAX_NV * HC_MAX_L];
+    for (int x = threadIdx.x; x < nv * L; x += 256) ws[x] = w[x];
+    __syncthreads();
+    const int64_t n = B * d;
+    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < n; x += (int64_t)gridDim.x * 256) {
+        const int64_t b = x / d;
+        const int col = (int)(x - b * d);
+        float acc[VC_MAX_NV];
+#pragma unroll
+        for (int v = 0; v < VC_MAX_NV; ++v) acc[v] = 0.0f;
+        const float* ep = e + b * L * d + col;
+        for (int l = 0; l < L; ++l) {
+            const float ev = ep[(int64_t)l * d];
+#pragma unroll
+            for (int v = 0; v < VC_MAX_NV; ++v)
+                if (v < nv) acc[v] = fmaf(ws[v * L + l], ev, acc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < VC_MAX_NV; ++v)
+            if (v < nv) out[x * nv + v] = acc[v] + bias[v];
+    }
+}
+
+// backward: ge[b, l, col] = sum_v w[v, l] g[b, col, v] (overwritten); partial[block, v, l] = this block's share of
+// dLoss/dw[v, l] = sum_{b, col} g[b, col, v] e[b, l, col], column l = L holds the bias gradient sum g[b, col, v].
+// Wave-level shuffles, lane 0 adds into the wave's LDS row in a fixed order; waves and blocks are summed in index order.
+__global__ __launch_bounds__(256) void vconv_bwd_kernel(const float* __restrict__ e, const float* __restrict__ w,
+                                                        const float* __restrict__ g, int64_t B, int L, int d, int nv,
+                                                        float* __restrict__ ge, float* __restrict__ partial) {
+    __shared__ float ws[VC_MAX_NV * HC_MAX_L];
+    __shared__ float wacc[4][VC_MAX_NV * (HC_MAX_L + 1)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int L1 = L + 1;
+    for (int x = threadIdx.x; x < nv * L; x += 256) ws[x] = w[x];
+    for (int x = threadIdx.x; x < 4 * VC_MAX_NV * (HC_MAX_L + 1); x += 256) (&wacc[0][0])[x] = 0.0f;
+    __syncthreads();
+    const int64_t n = B * d;
+    const int64_t n_up = (n + 255) / 256 * 256;          // whole waves take part in the shuffles
+    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < n_up; x += (int64_t)gridDim.x * 256) {
+        const bool live = x < n;
+        const int64_t b = live ? x / d : 0;
+        const int col = live ? (int)(x - b * d) : 0;
+        float gv[VC_MAX_NV];
+#pragma unroll
+        for (int v = 0; v < VC_MAX_NV; ++v) gv[v] = (live && v < nv) ? g[x * nv + v] : 0.0f;
+        const float* ep = e + b * L * d + col;
+        float* gp = ge + b * L * d + col;
+        for (int l = 0; l <= L; ++l) {
+            const float ev = l < L ? (live ? ep[(int64_t)l * d] : 0.0f) : 1.0f;
+            if (l < L && live) {
+                float s = 0.0f;
+#pragma unroll
+                for (int v = 0; v < VC_MAX_NV; ++v)
+                    if (v < nv) s = fmaf(ws[v * L + l], gv[v], s);
+                gp[(int64_t)l * d] = s;
+            }
+#pragma unroll
+            for (int v = 0; v < VC_MAX_NV; ++v)
+                if (v < nv) {
+                    float p = gv[v] * ev;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) p += __shfl_down(p, o, 64);
+                    if (lane == 0) wacc[wave][v * L1 + l] += p;
+                }
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < nv * L1; x += 256)
+        partial[(int64_t)blockIdx.x * nv * L1 + x] = ((wacc[0][x] + wacc[1][x]) + wacc[2][x]) + wacc[3][x];
+}
+
 static int hc_check(const char* who, int64_t B, int32_t L, int32_t C, int32_t d) {
     DR_REQUIRE(B >= 0 && L >= 1 && L <= HC_MAX_L && C >= 1 && C <= HC_MAX_C && d >= 1 && d <= HC_MAX_D,
                "%s: need B >= 0, 1 <= L <= %d, 1 <= C <= %d, 1 <= d <= %d (got B=%lld L=%d C=%d d=%d)", who, HC_MAX_L,
@@ -382,6 +461,35 @@ extern "C" int32_t dr_caser_hconv_direct_f32(const float* e, const float* W, con
     DR_LAUNCH_NAMED("hconv_direct_fwd_kernel", hconv_direct_fwd_kernel, dim3((unsigned)(nsg * L)), dim3(256), 0,
                     (hipStream_t)stream, e, W, bias, B, (int)L, (int)C, (int)d, (int)nsg, out, arg);
     DR_CHECK_LAUNCH("hconv_direct_fwd_kernel");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_caser_vconv_forward_f32(const float* e, const float* w, const float* bias, int64_t B, int32_t L,
+                                              int32_t d, int32_t nv, float* out, void* stream) {
+    DR_REQUIRE(B >= 0 && L >= 1 && L <= HC_MAX_L && d >= 1 && nv >= 1 && nv <= VC_MAX_NV,
+               "dr_caser_vconv_forward_f32: need 1 <= L <= %d, 1 <= n_v <= %d", HC_MAX_L, VC_MAX_NV);
+    if (B == 0) return DR_OK;
+    DR_REQUIRE(e && w && bias && out, "dr_caser_vconv_forward_f32: NULL pointer");
+    DR_LAUNCH(vconv_fwd_kernel, dim3(grid_for(B * d, 256)), dim3(256), 0, (hipStream_t)stream, e, w, bias, B, (int)L,
+              (int)d, (int)nv, out);
+    DR_CHECK_LAUNCH("vconv_fwd_kernel");
+    return DR_OK;
+}
+
+extern "C" int32_t dr_caser_vconv_backward_f32(const float* e, const float* w, const float* g, int64_t B, int32_t L,
+                                               int32_t d, int32_t nv, int32_t S, float* ge, float* partial,
+                                               void* stream) {
+    DR_REQUIRE(B >= 0 && L >= 1 && L <= HC_MAX_L && d >= 1 && nv >= 1 && nv <= VC_MAX_NV && S >= 1 && S <= 65535,
+               "dr_caser_vconv_backward_f32: need 1 <= L <= %d, 1 <= n_v <= %d, 1 <= S <= 65535", HC_MAX_L, VC_MAX_NV);
+    DR_REQUIRE(partial != nullptr, "dr_caser_vconv_backward_f32: partial is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        DR_HIP(hipMemsetAsync(partial, 0, (size_t)S * nv * (L + 1) * 4, st));
+        return DR_OK;
+    }
+    DR_REQUIRE(e && w && g && ge, "dr_caser_vconv_backward_f32: NULL pointer");
+    DR_LAUNCH(vconv_bwd_kernel, dim3(S), dim3(256), 0, st, e, w, g, B, (int)L, (int)d, (int)nv, ge, partial);
+    DR_CHECK_LAUNCH("vconv_bwd_kernel");
     return DR_OK;
 }
 

@@ -675,6 +675,42 @@ def caser_hconv_backward(e, W, arg, gout, C):
     return ge, gW, gbias
 
 
+VC_MAX_NV = 16
+
+
+def caser_vconv_forward(e, w, bias):
+    """Caser.py:118-130: e [B, L, d], w [n_v, L], bias [n_v] -> out [B, d * n_v] (column col * n_v + v)."""
+    e = _req(e, torch.float32, "e", 3)
+    w = _req(w, torch.float32, "w", 2)
+    bias = _req(bias, torch.float32, "bias", 1)
+    B, L, d = e.shape
+    nv = w.shape[0]
+    if w.shape[1] != L or bias.numel() != nv:
+        raise ValueError("caser_vconv_forward: w must be [n_v, L], bias [n_v]")
+    out = torch.empty((B, d * nv), dtype=torch.float32, device=e.device)
+    check(_abi.lib().dr_caser_vconv_forward_f32(_ptr(e), _ptr(w), _ptr(bias), B, L, d, nv, _ptr(out), _stream()),
+          "dr_caser_vconv_forward_f32")
+    return out
+
+
+def caser_vconv_backward(e, w, g):
+    """-> (ge [B, L, d], gw [n_v, L], gbias [n_v]) from g [B, d * n_v]."""
+    e = _req(e, torch.float32, "e", 3)
+    w = _req(w, torch.float32, "w", 2)
+    g = _req(g, torch.float32, "g", 2)
+    B, L, d = e.shape
+    nv = w.shape[0]
+    if g.shape != (B, d * nv) or w.shape[1] != L:
+        raise ValueError("caser_vconv_backward: g must be [B, d * n_v], w [n_v, L]")
+    S = max(1, min(1024, (B * d + 255) // 256))
+    ge = torch.empty_like(e)
+    partial = torch.empty((S, nv, L + 1), dtype=torch.float32, device=e.device)
+    check(_abi.lib().dr_caser_vconv_backward_f32(_ptr(e), _ptr(w), _ptr(g), B, L, d, nv, S, _ptr(ge), _ptr(partial),
+                                                 _stream()), "dr_caser_vconv_backward_f32")
+    tot = partial.sum(0)
+    return ge, tot[:, :L].contiguous(), tot[:, L].contiguous()
+
+
 # ------------------------------------------------------------------ sequence models: interaction + loss
 SEQ_LOSS_HINGE, SEQ_LOSS_BPR = 0, 1
 SEQ_MAX_SLOTS = 64

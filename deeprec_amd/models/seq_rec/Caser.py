@@ -58,13 +58,33 @@ class _HConv(torch.autograd.Function):
         return ge, gW, gb, None
 
 
+class _VConv(torch.autograd.Function):
+    """Caser.py:118-130: dr_caser_vconv_forward_f32 / _backward_f32 (one pass over the slab each way)."""
+
+    @staticmethod
+    def forward(ctx, e, w, bias):
+        e, w2 = e.contiguous(), w.reshape(w.shape[0], -1).contiguous()
+        ctx.save_for_backward(e, w2)
+        ctx.wshape = w.shape
+        return K.caser_vconv_forward(e, w2, bias.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        e, w2 = ctx.saved_tensors
+        ge, gw, gb = K.caser_vconv_backward(e, w2, g.contiguous())
+        return ge, gw.reshape(ctx.wshape), gb
+
+
 def caser_convs_fused(e, conv_v_w, conv_v_b, hw_cat, hb_cat, n_h):
     """caser_convs with the horizontal block on the HIP kernels: hw_cat [n_h L (L+1) / 2, d] holds every height's
     filters (row n_h h (h-1) / 2 + c h + r), hb_cat [n_h L] their biases in output order."""
     B, L, d = e.shape
     n_v = conv_v_w.shape[0]
-    out_v = torch.matmul(conv_v_w[:, 0, :, 0], e) + conv_v_b[None, :, None]
-    return torch.cat((out_v.permute(0, 2, 1).reshape(B, n_v * d), _HConv.apply(e, hw_cat, hb_cat, n_h)), 1)
+    if n_v <= K.VC_MAX_NV:
+        out_v = _VConv.apply(e, conv_v_w, conv_v_b)
+    else:
+        out_v = (torch.matmul(conv_v_w[:, 0, :, 0], e) + conv_v_b[None, :, None]).permute(0, 2, 1).reshape(B, n_v * d)
+    return torch.cat((out_v, _HConv.apply(e, hw_cat, hb_cat, n_h)), 1)
 
 
 class Caser(SeqBase):

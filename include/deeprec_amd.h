@@ -393,6 +393,14 @@ int32_t dr_caser_hconv_pool_f32(const float* G, int64_t ldg, const float* bias, 
                                 int32_t h0, int32_t h1, float* out, int32_t* arg, void* stream);
 int32_t dr_caser_hconv_direct_f32(const float* e, const float* W, const float* bias, int64_t B, int32_t L, int32_t C,
                                   int32_t d, float* out, int32_t* arg, void* stream);
+/* Vertical convolution (Caser.py:118-130): n_v filters [L, 1] over e [B, L, d]; out [B, d * n_v], column col * n_v + v
+ * (the reference's [B, d, n_v] flattening) = bias[v] + sum_l w[v, l] e[b, l, col].  Backward: g [B, d * n_v] ->
+ * ge [B, L, d] (overwritten) and partial [S, n_v, L + 1]: workgroup s's share of dLoss/dw (columns 0 .. L-1) and of
+ * dLoss/dbias (column L); the gradients are the sums over s.  1 <= L <= 64, 1 <= n_v <= 16; S = the launch's workgroups. */
+int32_t dr_caser_vconv_forward_f32(const float* e, const float* w, const float* bias, int64_t B, int32_t L, int32_t d,
+                                   int32_t nv, float* out, void* stream);
+int32_t dr_caser_vconv_backward_f32(const float* e, const float* w, const float* g, int64_t B, int32_t L, int32_t d,
+                                    int32_t nv, int32_t S, float* ge, float* partial, void* stream);
 int32_t dr_caser_hconv_backward_input_f32(const float* gout, const int32_t* arg, const float* W, int64_t B, int32_t L,
                                           int32_t C, int32_t d, float* ge, void* stream);
 int32_t dr_caser_hconv_backward_filter_f32(const float* gout, const int32_t* arg, const float* e, int64_t B, int32_t L,

@@ -957,6 +957,38 @@ def test_caser_hconv_forward_backward(dev, B, L, d, C):
             K.caser_hconv_forward(te, tW, tb, C, direct=True)
 
 
+@pytest.mark.parametrize("B,L,d,nv", [(1, 1, 1, 1), (37, 5, 30, 4), (300, 50, 128, 4), (9, 64, 150, 16), (700, 7, 64, 3)])
+def test_caser_vconv_forward_backward(dev, B, L, d, nv):
+    """dr_caser_vconv_forward_f32 / _backward_f32 (Caser.py:118-130) against float64 conv2d under autograd, in the
+    reference's [B, d, n_v] flattening; 1e-5 of each tensor's scale; two runs bit-identical."""
+    import torch.nn.functional as F
+    from deeprec_amd import kernels as K
+    g = torch.Generator().manual_seed(B + L + d)
+    e = torch.randn((B, L, d), generator=g) * 0.5
+    w = torch.randn((nv, L), generator=g) * 0.3
+    bias = torch.randn((nv,), generator=g) * 0.1
+    R = torch.randn((B, d * nv), generator=g)
+    e64, w64, b64 = (t.double().requires_grad_(True) for t in (e, w, bias))
+    ref = F.conv2d(e64[:, None], w64[:, None, :, None], b64)[:, :, 0, :]          # [B, n_v, d]
+    ref = ref.permute(0, 2, 1).reshape(B, d * nv)                                  # Caser.py:129-130
+    (ref * R.double()).sum().backward()
+    te, tw, tb, tR = e.to(dev), w.to(dev), bias.to(dev), R.to(dev)
+    out = K.caser_vconv_forward(te, tw, tb)
+    ge, gw, gb = K.caser_vconv_backward(te, tw, tR)
+
+    def close(name, got, want):
+        got, want = got.detach().cpu().double().numpy(), want.detach().numpy()
+        assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-30), name
+    close("out", out, ref)
+    close("ge", ge, e64.grad)
+    close("gw", gw, w64.grad)
+    close("gb", gb, b64.grad)
+    ge2, gw2, gb2 = K.caser_vconv_backward(te, tw, tR)
+    assert torch.equal(ge, ge2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    z = K.caser_vconv_backward(te[:0], tw, tR[:0])
+    assert z[0].shape == (0, L, d) and float(z[1].abs().max()) == 0.0
+
+
 def test_caser_hconv_empty_batch_and_limits(dev):
     from deeprec_amd import kernels as K
     from deeprec_amd._abi import DeepRecError
