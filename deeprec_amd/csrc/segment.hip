@@ -88,7 +88,8 @@ static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
     L->msrc = take(nn * 4);
     L->mcoef = take(nn * 4);
     L->solo = take(nn);  // one byte per ORIGINAL position: its segment has exactly one contribution (BPR plans)
-    L->multi = take((nn / 2 + 1) * 4);   // segments with 2 .. LONG_SEG contributions (arbitrary order), count in hdr[4]
+    L->multi = take((nn / 2 + 1) * 16);  // int4 {segment, key, first sorted position, length} of every segment with
+                                         // 2 .. LONG_SEG contributions (arbitrary order), count in hdr[4]
     L->long_cnt = take(max_long * 4);    // blocks of a long segment summed so far (bpr_tail_kernel), zero between uses
     L->partials = take(L->partial_rows * (int64_t)(k_max > 0 ? k_max : 1) * 4);
     L->total = off;
@@ -218,9 +219,10 @@ __global__ void plan_empty_kernel(int32_t* hdr, int32_t* seg_start) {
 
 // list the long segments and hand each a contiguous range of partial rows (allocation order is
 // arbitrary; it never influences a result)
-__global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restrict__ seg_start, int32_t* __restrict__ hdr,
+__global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restrict__ seg_start,
+                                                        const int32_t* __restrict__ uniq, int32_t* __restrict__ hdr,
                                                         int32_t* __restrict__ long_seg, int32_t* __restrict__ long_cb,
-                                                        int32_t* __restrict__ part_owner, int32_t* __restrict__ multi,
+                                                        int32_t* __restrict__ part_owner, int4* __restrict__ multi,
                                                         int32_t* __restrict__ long_cnt, int64_t n) {
     // The three counters live in one cache line and device-scope atomics on one line are served one at a time by the
     // memory side of this multi-XCD part (~8 ns each: 20 k per-row atomics made this kernel 22 us).  So: ONE atomic per
@@ -231,7 +233,8 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t s0 = (int64_t)blockIdx.x * 256; s0 < nseg; s0 += stride) {   // block-uniform trip count
         const int64_t s = s0 + threadIdx.x;
-        const int len = s < nseg ? seg_start[s + 1] - seg_start[s] : 0;
+        const int first = s < nseg ? seg_start[s] : 0;
+        const int len = s < nseg ? seg_start[s + 1] - first : 0;
         // long rows: count and block total of this wavefront, one atomic each
         const bool is_long = len > LONG_SEG;
         const unsigned long long ml = __ballot(is_long);
@@ -273,7 +276,8 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
             }
         }
         __syncthreads();
-        if (is_multi) multi[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
+        // one 16-byte descriptor per row: the tail kernel then needs ONE load where it walked multi -> uniq / seg_start
+        if (is_multi) multi[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = make_int4((int)s, uniq[s], first, len);
         __syncthreads();
     }
 }
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
                                                               int32_t* __restrict__ hdr, int32_t* __restrict__ long_seg,
                                                               int32_t* __restrict__ long_cb,
                                                               int32_t* __restrict__ part_owner,
-                                                              int32_t* __restrict__ multi,
+                                                              int4* __restrict__ multi,
                                                               int32_t* __restrict__ long_cnt) {
     using Sort = rocprim::block_radix_sort<uint32_t, SMALL_T, SMALL_IPT, int32_t>;
     using Scan = rocprim::block_scan<int, SMALL_T>;
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
             long_cnt[l] = 0;
             for (int c = 0; c < nch; ++c) part_owner[cb + c] = l;
         } else if (len >= 2) {
-            multi[atomicAdd(&sh_multi, 1)] = s;
+            multi[atomicAdd(&sh_multi, 1)] = make_int4(s, uniq[s], seg_start[s], len);
         }
     }
     __syncthreads();
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
 // order, the same operations per row as seg_update_kernel / seg_long_*_kernel: bit-identical results.
 struct TailArgs {
     SegArgs p, q;
-    const int32_t* multi;
+    const int4* multi;
     int32_t* long_cnt;
 };
 
@@ -671,24 +675,34 @@ __global__ __launch_bounds__(256) void bpr_tail_kernel(TailArgs t) {
                 vstore<V>(a.partials + (int64_t)w * k + c * V, acc);
             }
         } else {
-            const int s = t.multi[w - nparts];
-            const SegArgs& a = (s < split) ? t.p : t.q;
-            const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
+            const int4 dsc = t.multi[w - nparts];    // {segment, key, first sorted position, length}
+            const SegArgs& a = (dsc.x < split) ? t.p : t.q;
+            const uint32_t r = (uint32_t)dsc.y - a.id_lo;
             if ((int64_t)r >= a.rows) continue;
-            const int b = a.seg_start[s];
-            const int len = a.seg_start[s + 1] - b;  // 2 .. LONG_SEG
-            int si[4];
+            const int b = dsc.z;
+            const int len = dsc.w;  // 2 .. LONG_SEG
+            int si[4], sp[4];
             float cf[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 si[q] = -1;
-                cf[q] = 1.0f;
+                sp[q] = 0;
                 if (q < len) {
                     si[q] = a.msrc[b + q];
-                    if (a.coef && si[q] >= 0) cf[q] = a.coef[a.spos[b + q] - a.pos_lo];
+                    if (a.coef) sp[q] = a.spos[b + q];
                 }
             }
+            const int ns = KIND == DR_OPT_ADAM ? 2 : kind_slots(a.kind);
             for (int c = lane; c < cpr; c += LPR) {
+                // the destination row's (w, m, v) are requested BEFORE the source-row indices above are waited for:
+                // descriptor -> {indices, destination row} -> {source rows, coefficients} = three round trips per row
+                const int64_t off = (int64_t)r * k + c * V;
+                float wv[V], s0[V], s1[V];
+                vload<V>(wv, a.table + off);
+                if (ns >= 1) vload<V>(s0, a.slot0 + off);
+                if (ns >= 2) vload<V>(s1, a.slot1 + off);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cf[q] = (a.coef && si[q] >= 0) ? a.coef[sp[q] - a.pos_lo] : 1.0f;
                 float v[4][V], tot[V];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -703,7 +717,7 @@ __global__ __launch_bounds__(256) void bpr_tail_kernel(TailArgs t) {
                     }
 #pragma unroll
                 for (int x = 0; x < V; ++x) tot[x] = 0.0f + tot[x];
-                apply_row<V, KIND>(a, r, c, tot);
+                apply_row_loaded<V, KIND>(a, r, c, tot, wv, s0, s1);
             }
         }
     }
@@ -731,6 +745,18 @@ __global__ __launch_bounds__(256) void bpr_tail_combine_kernel(TailArgs t) {
 #pragma unroll
             for (int x = 0; x < V; ++x) tot[x] = 0.0f;
             int ch = 0;
+            // the Zipf-head rows have hundreds of partial rows and ONE sub-wave adds them in order: 32 loads in flight per
+            // round trip (same sequence of additions), or the longest row alone takes 20 round trips
+            for (; ch + 32 <= nch; ch += 32) {
+                float v[32][V];
+#pragma unroll
+                for (int q = 0; q < 32; ++q) vload<V>(v[q], part + (int64_t)(ch + q) * k + c * V);
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[q][x];
+                }
+            }
             for (; ch + 8 <= nch; ch += 8) {
                 float v[8][V];
 #pragma unroll
@@ -942,12 +968,12 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
         if (n <= 256 * SMALL_IPT)
             DR_LAUNCH(plan_small_kernel<256>, dim3(1), dim3(256), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
                       split_key, keys_out, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
-                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int32_t*)(base + L.multi),
+                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int4*)(base + L.multi),
                       (int32_t*)(base + L.long_cnt));
         else
             DR_LAUNCH(plan_small_kernel<1024>, dim3(1), dim3(1024), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
                       split_key, keys_out, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
-                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int32_t*)(base + L.multi),
+                      (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int4*)(base + L.multi),
                       (int32_t*)(base + L.long_cnt));
         DR_CHECK_LAUNCH("plan_small_kernel");
         return DR_OK;
@@ -965,8 +991,8 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
               split_key);
     DR_CHECK_LAUNCH("plan_finalize_kernel");
     if (n >= 2) {
-        DR_LAUNCH(plan_long_kernel, dim3(grid), dim3(256), 0, st, seg_start, hdr, (int32_t*)(base + L.long_seg),
-                  (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int32_t*)(base + L.multi),
+        DR_LAUNCH(plan_long_kernel, dim3(grid), dim3(256), 0, st, seg_start, (const int32_t*)uniq, hdr, (int32_t*)(base + L.long_seg),
+                  (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int4*)(base + L.multi),
                   (int32_t*)(base + L.long_cnt), n);
         DR_CHECK_LAUNCH("plan_long_kernel");
     }
@@ -1175,7 +1201,7 @@ int bpr_tail_launch(float* P, float* Ps0, float* Ps1, int64_t nu, float* Q, floa
     rc = seg_fill(t.p, L, base, P, Ps0, Ps1, nu, k, stash, B, nullptr, nullptr, n, plan, opt->kind, opt, st, true,
                   SegSel{0, 1, 0}, nullptr, true);
     if (rc != DR_OK) return rc;
-    t.multi = (const int32_t*)(base + L.multi);
+    t.multi = (const int4*)(base + L.multi);
     t.long_cnt = (int32_t*)(base + L.long_cnt);
     RowShape s = row_shape(k);
     bool ok = false;
