@@ -15,6 +15,9 @@
 
 namespace dr {
 
+#ifndef DR_ABL
+#define DR_ABL 0   // timing ablations of score_kernel_t1 (tools/build_abl.sh); 0 = the product
+#endif
 constexpr int TU = 64;   // users per block tile
 constexpr int TI = 64;   // items per tile step
 constexpr int KC = 128;  // k-chunk staged in LDS
@@ -533,6 +536,13 @@ __device__ __forceinline__ void store_chunk(float* __restrict__ d, const float (
 // k-steps, each group of 8 k-steps read one group ahead of its MFMAs.  ng = number of groups that hold data.
 template <int NG>
 __device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const float* __restrict__ pb, int ng) {
+#if DR_ABL == 6   // timing experiment: two independent accumulators (changes the summation order)
+    f32x16 acc2;
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+#define DR_ACC2 acc2
+#else
+#define DR_ACC2 acc
+#endif
     float4 b[2][2];
     b[0][0] = *reinterpret_cast<const float4*>(pb);
     b[0][1] = *reinterpret_cast<const float4*>(pb + 8);
@@ -545,13 +555,13 @@ __device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const
         __builtin_amdgcn_sched_barrier(0); /* keep the next group's reads ahead of this group's MFMAs */          \
         const float4 x = b[(gq) & 1][0], y = b[(gq) & 1][1];                                                       \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 0], x.x, acc, 0, 0, 0);                         \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 1], x.y, acc, 0, 0, 0);                         \
+        DR_ACC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 1], x.y, DR_ACC2, 0, 0, 0);                 \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 2], x.z, acc, 0, 0, 0);                         \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 3], x.w, acc, 0, 0, 0);                         \
+        DR_ACC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 3], x.w, DR_ACC2, 0, 0, 0);                 \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 4], y.x, acc, 0, 0, 0);                         \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 5], y.y, acc, 0, 0, 0);                         \
+        DR_ACC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 5], y.y, DR_ACC2, 0, 0, 0);                 \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 6], y.z, acc, 0, 0, 0);                         \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 7], y.w, acc, 0, 0, 0);                         \
+        DR_ACC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 7], y.w, DR_ACC2, 0, 0, 0);                 \
     }
     if (ng == NG) {  // full chunk: one straight-line block
 #pragma unroll
@@ -563,6 +573,10 @@ __device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const
         }
     }
 #undef DR_MFMA_GROUP
+#if DR_ABL == 6
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+#endif
+#undef DR_ACC2
 }
 
 template <int KS>
@@ -677,15 +691,27 @@ constexpr int T1_MASKW = T1_CANDW + 2 * TU;       // [TU] u64
 constexpr int T1_TSC = T1_MASKW + 2 * TU;         // [TU] held-out score (+inf: none)
 constexpr int T1_TID = T1_TSC + TU;               // [TU] held-out item id (-1: none)
 constexpr int T1_TCNT = T1_TID + TU;              // [TU] rank counters
-constexpr int T1_MISC = T1_TCNT + TU;             // [0] epoch of tau, [1..2] any-mask flags (tile parity)
-constexpr int T1_TOPV = T1_MISC + 4;              // [TU][K] scores, then [TU][K] ids
-static_assert((T1_CANDW % 2) == 0 && (T1_MASKW % 2) == 0 && (T1_TOPV % 4) == 0, "LDS alignment");
+constexpr int T1_MISC = T1_TCNT + TU;             // [0] epoch of tau, [1..2] masked entries of the tile (tile parity)
+constexpr int T1_MCAP = 32;                       // masked (row, column) entries listed per tile; more: the row words
+constexpr int T1_MLIST = T1_MISC + 4;             // [2][T1_MCAP] row << 8 | column
+constexpr int T1_TOPV = T1_MLIST + 2 * T1_MCAP;   // [TU][K] scores, then [TU][K] ids
+static_assert((T1_CANDW % 2) == 0 && (T1_MASKW % 2) == 0 && (T1_TOPV % 4) == 0 && (T1_MISC % 4) == 0, "LDS alignment");
 
-template <int KS, bool VEC>
+#if DR_ABL == 9   // phase trace of score_kernel_t1 (tools/score_trace.py): wave 0 of every block, first DBG_T tiles
+constexpr int DBG_T = 96, DBG_STRIDE = 4 + 8 * DBG_T;
+__device__ long long dbg_trace[4096 * DBG_STRIDE];
+#define DR_TRACE(slot) if (tid == 0 && t - t_begin >= 2000 && t - t_begin < 2000 + DBG_T) dbg_row[4 + 8 * (t - t_begin - 2000) + (slot)] = (long long)__builtin_readcyclecounter()
+#else
+#define DR_TRACE(slot)
+#endif
+template <int KS, bool VEC, bool AFFINE>
 __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
     using G = Geo<KS, VEC>;
     static_assert(KS <= KC / 2, "one k-chunk per tile");
     if (*a.mode_flag != 0) return;  // some user has several held-out items: score_kernel handles this call
+#if DR_ABL == 7
+    if (blockIdx.y & 1) __builtin_amdgcn_s_sleep(55);   // experiment: co-resident blocks out of phase
+#endif
     extern __shared__ __align__(16) float smem[];
     float* sI = smem;  // [TI][LDP], k-permuted (see LDP)
     float* base = smem + TI * LDP;
@@ -697,6 +723,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
     int* tidl = reinterpret_cast<int*>(base + T1_TID);
     int* tcnt = reinterpret_cast<int*>(base + T1_TCNT);
     int* misc = reinterpret_cast<int*>(base + T1_MISC);
+    int* mlist = reinterpret_cast<int*>(base + T1_MLIST);
     const int K = a.K;
     float* topv = base + T1_TOPV;
     int* topi = reinterpret_cast<int*>(base + T1_TOPV + TU * K);
@@ -711,6 +738,15 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
     if (t_end > a.ntiles) t_end = a.ntiles;
     const int k = a.k;
 
+#if DR_ABL == 9
+    long long* dbg_row = dbg_trace + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % 4096) * DBG_STRIDE;
+    if (tid == 0) {
+        dbg_row[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        dbg_row[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        dbg_row[2] = blockIdx.x;
+        dbg_row[3] = blockIdx.y;
+    }
+#endif
     float areg[KS];
     load_areg<KS>(areg, a, u0, wu, lane);
     for (int e = tid; e < TI * LDP; e += 256) sI[e] = 0.0f;
@@ -725,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
     int cur = 0, cur_end = 0, nxt = 0x7fffffff, nxt2 = 0x7fffffff;
     if (tid < TU) {
         const int64_t u = u0 + tid;
-        tau[tid] = (u < a.Nu) ? __builtin_nanf("") : INFINITY;
+        tau[tid] = (u < a.Nu) ? -INFINITY : INFINITY;   // -inf: list not full yet
         candw[tid] = 0ull;
         maskw[tid] = 0ull;
         tcnt[tid] = 0;
@@ -755,9 +791,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
         nxt = cur < cur_end ? a.train_idx[cur] : 0x7fffffff;
         nxt2 = cur + 1 < cur_end ? a.train_idx[cur + 1] : 0x7fffffff;
     }
-    const bool affine = a.uadd || a.iadd || a.cdot != 1.0f;
     float ua[16];
-    load_uadd(ua, a, u0, wu, lane);
+    if (AFFINE) load_uadd(ua, a, u0, wu, lane);
     const int mycol = wi * 32 + (lane & 31);
     const int rbase = wu * 32 + 4 * (lane >> 5);   // row of accumulator element r = rbase + (r&3) + 8*(r>>2)
 
@@ -788,7 +823,15 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
 
     for (int t = t_begin; t <= t_end; ++t) {   // iteration t_end only folds the last tile's candidates
         const int64_t i0 = (int64_t)t * TI;
+#if DR_ABL != 4
+        // Explicit lgkmcnt(0): on the loop's back edge the compiler emitted s_barrier with this wave's last candidate
+        // store + ds_or still in flight (no s_waitcnt in the latch), and the row's owner -- another wave -- then read the
+        // candidate word without the bit: lost top-K entries for the rows written last (found with tools/_dbg, 6-12 of
+        // 300 users wrong, different ones every run).
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         __syncthreads();  // A: tile t-1's candidates are visible, every wave is done with the item tile in LDS
+#endif
+        DR_TRACE(0);
         if (owner) {
             unsigned long long m = candw[orow];
             if (m) {  // fold tile t-1's candidates of this row into its sorted list
@@ -822,34 +865,80 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
         if (owner) {  // masked (train) items of tile t for this row
             unsigned long long m = 0ull;
             const int hi = (int)i0 + TI;
-            if (nxt < hi) {
-                m |= 1ull << (nxt - (int)i0);
+            while (nxt < hi) {   // rare: ~ one masked item per 64-row tile
+                const int c = nxt - (int)i0;
+                m |= 1ull << c;
+                const int e = atomicAdd(&misc[1 + (t & 1)], 1);
+                if (e < T1_MCAP) mlist[(t & 1) * T1_MCAP + e] = (orow << 8) | c;
                 ++cur;
                 nxt = nxt2;
                 nxt2 = cur + 1 < cur_end ? a.train_idx[cur + 1] : 0x7fffffff;
-                while (nxt < hi) {
-                    m |= 1ull << (nxt - (int)i0);
-                    ++cur;
-                    nxt = nxt2;
-                    nxt2 = cur + 1 < cur_end ? a.train_idx[cur + 1] : 0x7fffffff;
-                }
-                atomicOr(&misc[1 + (t & 1)], 1);
             }
             maskw[orow] = m;
         }
+        DR_TRACE(1);
         if (tid == 0) misc[1 + ((t + 1) & 1)] = 0;
+#if DR_ABL != 3
         if (live0) store_chunk<KS, VEC, G::NPRE>(dst, pre);
+#endif
+        DR_TRACE(2);
         const float ia = ia_next;
+#if DR_ABL != 4
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): tile, mask list and tau stores of this wave have landed
         __syncthreads();  // B
+#endif
+        DR_TRACE(3);
         if (t + 1 < t_end) {
+#if DR_ABL != 3
             prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, i0 + TI, a.Ni, k, 0, r0, gc0);
-            ia_next = load_iadd(a, i0 + TI + mycol);
+#endif
+            if (AFFINE) ia_next = load_iadd(a, i0 + TI + mycol);
+        }
+        // everything the selection needs from LDS is requested BEFORE the MFMA chain (it was published before barrier
+        // B): the epoch of tau, the number of masked entries of this tile and the first four of them, refreshed taus
+        const int4 mi = *reinterpret_cast<const int4*>(misc);
+        const int nm = (t & 1) ? mi.z : mi.y;
+        int4 me = make_int4(-1, -1, -1, -1);
+        if (nm) me = *reinterpret_cast<const int4*>(mlist + (t & 1) * T1_MCAP);
+        if (mi.x != my_epoch) {
+            my_epoch = mi.x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tauR[r] = tau[rbase + (r & 3) + 8 * (r >> 2)];
         }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#if DR_ABL == 2
+        {
+            const int ngr = (k + 15) >> 4;
+            for (int gq = 0; gq < KS / 8; ++gq)
+                if (gq < ngr) {
+                    const float4 x = *reinterpret_cast<const float4*>(pb + gq * 16), y = *reinterpret_cast<const float4*>(pb + gq * 16 + 8);
+                    acc[gq & 15] += areg[gq * 8] * x.x + areg[gq * 8 + 1] * x.y + areg[gq * 8 + 4] * y.x + areg[gq * 8 + 7] * y.w;
+                }
+        }
+#else
+        // The other block's wave on this SIMD does its selection / staging (plain VALU work) while this wave streams
+        // MFMAs through the same pipe: at equal priority every one of its VALU instructions queues behind a 64-cycle
+        // MFMA.  The non-MFMA part of a tile runs at raised priority so that it slips in after the MFMA in flight.
+#if DR_ABL != 12
+        __builtin_amdgcn_s_setprio(0);
+#endif
         mfma_chunk<KS / 8>(acc, areg, pb, (k + 15) >> 4);
-        if (affine) {
+#if DR_ABL != 12
+        __builtin_amdgcn_s_setprio(3);
+#endif
+#endif
+        DR_TRACE(4);
+#if DR_ABL == 8   // experiment: what does one more plain VALU instruction cost? (64 dependent v_add per tile)
+        {
+            float dmy = acc[0];
+#pragma unroll
+            for (int z = 0; z < 64; ++z) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dmy));
+            if (dmy == 123.456f) cnt[0] += 1;
+        }
+#endif
+        if (AFFINE) {
             const float cd = a.cdot;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -858,52 +947,60 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
                 acc[r] = sc + ia;
             }
         }
-        // entries that must be looked at by nobody: masked train items, columns beyond the catalog
-        unsigned dead = 0u;
-        const int nc = (a.Ni - i0 < TI) ? (int)(a.Ni - i0) : TI;
-        if (misc[1 + (t & 1)] != 0 || nc != TI) {
-            if (mycol >= nc) dead = 0xffffu;
+        // entries that must be looked at by nobody (masked train items, columns beyond the catalog) become -inf: they
+        // beat nothing, count for nothing and tie with nothing, so every tile takes the same straight-line path below
+        const bool ragged = (t == a.ntiles - 1) && ((int)a.Ni & (TI - 1)) != 0;
+        if (DR_ABL != 5 && (nm != 0 || ragged)) {                      // uniform
+            if (DR_ABL != 10 && nm <= T1_MCAP && !ragged) {
+                unsigned deadbits = 0u;
+                for (int e = 0; e < nm; ++e) {
+                    const int ent = e == 0 ? me.x : (e == 1 ? me.y : (e == 2 ? me.z : (e == 3 ? me.w : mlist[(t & 1) * T1_MCAP + e])));
+                    const int rr = (ent >> 8) - rbase;                 // this lane's rows: rr in {0..3, 8..11, 16..19, 24..27}
+                    if ((ent & 255) == mycol && (unsigned)rr < 32u && !(rr & 4)) deadbits |= 1u << ((rr & 3) | ((rr >> 3) << 2));
+                }
+                if (deadbits) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned long long m = maskw[rbase + (r & 3) + 8 * (r >> 2)];
-                dead |= (unsigned)((m >> mycol) & 1ull) << r;
+                    for (int r = 0; r < 16; ++r)
+                        if ((deadbits >> r) & 1u) acc[r] = -INFINITY;
+                }
+            } else {                                                   // many masked items in one tile / the last tile
+                const int nc = ragged ? ((int)a.Ni & (TI - 1)) : TI;
+                const bool beyond = mycol >= nc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned long long m = maskw[rbase + (r & 3) + 8 * (r >> 2)];
+                    if (beyond || ((m >> mycol) & 1ull)) acc[r] = -INFINITY;
+                }
             }
         }
-        const int ep = misc[0];
-        if (ep != my_epoch) {
-            my_epoch = ep;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tauR[r] = tau[rbase + (r & 3) + 8 * (r >> 2)];
-        }
+        DR_TRACE(5);
         bool any = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float sc = acc[r];
-            any |= !(sc <= tauR[r]);      // beats the K-th best, or the list is not full yet (tau = NaN)
+            cnt[r] += (sc > stR[r]) ? 1 : 0;
+#if DR_ABL != 1
+            any |= (sc > tauR[r]);        // beats the K-th best (tau = -inf while the list is not full)
             any |= (sc == stR[r]);        // tie with the held-out item: decided by item id
+#endif
         }
-        if (dead == 0u && !any) {         // the usual tile: count and go on
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cnt[r] += (acc[r] > stR[r]) ? 1 : 0;
-        } else {
+        if (any) {                        // rare after the first tiles: only the lanes / entries concerned do anything
             const int item = (int)i0 + mycol;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if ((dead >> r) & 1u) continue;
                 const float sc = acc[r];
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (sc > stR[r]) {
-                    ++cnt[r];
-                } else if (sc == stR[r]) {
+                if (sc == stR[r]) {
                     const int ct = tidl[row];
                     if (ct >= 0 && item < ct) ++cnt[r];
                 }
-                if (!(sc <= tauR[r]) && sc == sc) {
+                if (sc > tauR[r]) {
                     sS[row * LDS_S + mycol] = sc;
                     atomicOr(&candw[row], 1ull << mycol);
                 }
             }
         }
+        DR_TRACE(6);
     }
     // per-lane rank counts -> rows -> global
 #pragma unroll
@@ -1191,13 +1288,20 @@ static int launch_score_regs(const ScoreArgs& a, dim3 grid, hipStream_t st) {
 
 static size_t t1_smem_bytes(int K) { return ((size_t)TI * LDP + T1_TOPV + (size_t)2 * TU * K) * 4; }
 
-template <int KS, bool VEC>
-static int launch_score_t1_k(const ScoreArgs& a, dim3 grid, hipStream_t st) {
+template <int KS, bool VEC, bool AFFINE>
+static int launch_score_t1_ka(const ScoreArgs& a, dim3 grid, hipStream_t st) {
     const size_t smem = t1_smem_bytes(a.K);
-    DR_HIP(hipFuncSetAttribute((const void*)score_kernel_t1<KS, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DR_LAUNCH((score_kernel_t1<KS, VEC>), grid, dim3(256), smem, st, a);
+    DR_HIP(hipFuncSetAttribute((const void*)score_kernel_t1<KS, VEC, AFFINE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    DR_LAUNCH((score_kernel_t1<KS, VEC, AFFINE>), grid, dim3(256), smem, st, a);
     DR_CHECK_LAUNCH("score_kernel_t1");
     return DR_OK;
+}
+template <int KS, bool VEC>
+static int launch_score_t1_k(const ScoreArgs& a, dim3 grid, hipStream_t st) {
+    // plain dot scores (the common evaluation) skip the affine epilogue and its 16 per-row registers altogether
+    const bool affine = DR_ABL == 11 || a.uadd || a.iadd || a.cdot != 1.0f;
+    return affine ? launch_score_t1_ka<KS, VEC, true>(a, grid, st) : launch_score_t1_ka<KS, VEC, false>(a, grid, st);
 }
 static int launch_score_t1(const ScoreArgs& a, dim3 grid, hipStream_t st) {
     const bool vec = (a.k & 7) == 0;  // rows fetched as pairs of float4
@@ -1788,3 +1892,9 @@ extern "C" int32_t dr_score_rank_exact_f32(const float* U, const float* U2, int6
     DR_CHECK_LAUNCH("target_finalize_kernel");
     return DR_OK;
 }
+
+#if DR_ABL == 9
+extern "C" int32_t dr_debug_trace(void* dst, int64_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(dr::dbg_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
