@@ -472,7 +472,13 @@ __global__ __launch_bounds__(256) void score_kernel_anyk(ScoreArgs a) {
 // of a row (two float4) stores them as two ds_write_b128.  The permutation only moves values inside LDS: every
 // MFMA still receives k = 2j + h, so the accumulation order -- and every bit of the result -- is unchanged.
 constexpr int LDP = KC + 4;
-__device__ __forceinline__ constexpr int kpos(int c) { return (c & ~7) + ((c & 1) << 2) + ((c & 7) >> 1); }
+// Every second run of four 8-k groups has its even / odd halves swapped (bit 5 of k): a thread that stores the 8 k of
+// group g as two ds_write_b128 then hits 16-byte slot 2g + ((g >> 2) & 1) with the first and the other slot with the
+// second, so the eight lanes that one LDS cycle serves cover all 32 banks (unswizzled, lanes g and g + 4 collided: every
+// tile store ran at half rate, in the way of the co-resident block's operand reads).  Readers: mfma_chunk's pbx.
+__device__ __forceinline__ constexpr int kpos(int c) {
+    return (c & ~7) + (((c & 1) ^ ((c >> 5) & 1)) << 2) + ((c & 7) >> 1);
+}
 
 // Thread -> chunk element mapping, all compile-time: W floats per element (8 when k % 8 == 0, else 1), CPT
 // elements per row (power of two covering the widest chunk of this instantiation), thread th owns column
@@ -516,16 +522,18 @@ __device__ __forceinline__ void prefetch_chunk(float (&pre)[N], const float* __r
     }
 }
 
-// d = sI + r0 * LDP + (VEC ? g * 8 : kpos(g))
+// d = sI + r0 * LDP + (VEC ? g * 8 + 4 * ((g >> 2) & 1) : kpos(g)): where the even k of the thread's group go (VEC: the
+// odd k go to the other half of the group, d ^ 16 bytes)
 template <int KS, bool VEC, int N>
-__device__ __forceinline__ void store_chunk(float* __restrict__ d, const float (&pre)[N]) {
+__device__ __forceinline__ void store_chunk(float* __restrict__ d, float* __restrict__ dodd, const float (&pre)[N]) {
     using G = Geo<KS, VEC>;
 #pragma unroll
     for (int q = 0; q < G::PASSES; ++q) {
         if (VEC) {
-            float4* o = reinterpret_cast<float4*>(d + q * G::RPP * LDP);
-            o[0] = make_float4(pre[8 * q], pre[8 * q + 2], pre[8 * q + 4], pre[8 * q + 6]);      // even k
-            o[1] = make_float4(pre[8 * q + 1], pre[8 * q + 3], pre[8 * q + 5], pre[8 * q + 7]);  // odd k
+            *reinterpret_cast<float4*>(d + q * G::RPP * LDP) =
+                make_float4(pre[8 * q], pre[8 * q + 2], pre[8 * q + 4], pre[8 * q + 6]);          // even k
+            *reinterpret_cast<float4*>(dodd + q * G::RPP * LDP) =
+                make_float4(pre[8 * q + 1], pre[8 * q + 3], pre[8 * q + 5], pre[8 * q + 7]);      // odd k
         } else {
             d[q * G::RPP * LDP] = pre[q];
         }
@@ -535,33 +543,31 @@ __device__ __forceinline__ void store_chunk(float* __restrict__ d, const float (
 // 8 * NG MFMAs of one k-chunk.  pb = sI + column * LDP + 4 * (lane >> 5); B operands arrive as one float4 per four
 // k-steps, each group of 8 k-steps read one group ahead of its MFMAs.  ng = number of groups that hold data.
 template <int NG>
-__device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const float* __restrict__ pb, int ng) {
-#if DR_ABL == 6   // timing experiment: two independent accumulators (changes the summation order)
-    f32x16 acc2;
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
-#define DR_ACC2 acc2
-#else
-#define DR_ACC2 acc
-#endif
+__device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const float* __restrict__ pb,
+                                           const float* __restrict__ pbx, int ng) {
+    // B operands are requested one group (8 MFMAs, 512 cycles) ahead of their use (two groups ahead: no faster for
+    // k = 128, and the k = 256 instantiation spills more)
     float4 b[2][2];
+    // pb = sI + column * LDP + 4 * h, pbx = the same with the halves swapped (8-k groups 4..7, 12..15: see kpos)
+#define DR_PB(g_) ((((g_) >> 1) & 1) ? pbx : pb)   /* MFMA group g_ = 8-k groups 2 g_, 2 g_ + 1 */
     b[0][0] = *reinterpret_cast<const float4*>(pb);
     b[0][1] = *reinterpret_cast<const float4*>(pb + 8);
 #define DR_MFMA_GROUP(gq)                                                                                          \
     {                                                                                                              \
         if ((gq) + 1 < NG) {                                                                                       \
-            b[((gq) + 1) & 1][0] = *reinterpret_cast<const float4*>(pb + ((gq) + 1) * 16);                         \
-            b[((gq) + 1) & 1][1] = *reinterpret_cast<const float4*>(pb + ((gq) + 1) * 16 + 8);                     \
+            b[((gq) + 1) & 1][0] = *reinterpret_cast<const float4*>(DR_PB((gq) + 1) + ((gq) + 1) * 16);            \
+            b[((gq) + 1) & 1][1] = *reinterpret_cast<const float4*>(DR_PB((gq) + 1) + ((gq) + 1) * 16 + 8);        \
         }                                                                                                          \
         __builtin_amdgcn_sched_barrier(0); /* keep the next group's reads ahead of this group's MFMAs */          \
         const float4 x = b[(gq) & 1][0], y = b[(gq) & 1][1];                                                       \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 0], x.x, acc, 0, 0, 0);                         \
-        DR_ACC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 1], x.y, DR_ACC2, 0, 0, 0);                 \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 1], x.y, acc, 0, 0, 0);                         \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 2], x.z, acc, 0, 0, 0);                         \
-        DR_ACC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 3], x.w, DR_ACC2, 0, 0, 0);                 \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 3], x.w, acc, 0, 0, 0);                         \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 4], y.x, acc, 0, 0, 0);                         \
-        DR_ACC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 5], y.y, DR_ACC2, 0, 0, 0);                 \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 5], y.y, acc, 0, 0, 0);                         \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 6], y.z, acc, 0, 0, 0);                         \
-        DR_ACC2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 7], y.w, DR_ACC2, 0, 0, 0);                 \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[(gq) * 8 + 7], y.w, acc, 0, 0, 0);                         \
     }
     if (ng == NG) {  // full chunk: one straight-line block
 #pragma unroll
@@ -573,10 +579,7 @@ __device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const
         }
     }
 #undef DR_MFMA_GROUP
-#if DR_ABL == 6
-    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
-#endif
-#undef DR_ACC2
+#undef DR_PB
 }
 
 template <int KS>
@@ -628,8 +631,10 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
     const bool live0 = g * G::W < kc_first;
     const bool live1 = NCH > 1 && g * G::W < k - KC;
     const int gc0 = live0 ? g : 0, gc1 = live1 ? g : 0;
-    float* dst = sI + r0 * LDP + (VEC ? g * 8 : kpos(g));
+    float* dst = sI + r0 * LDP + (VEC ? g * 8 + 4 * ((g >> 2) & 1) : kpos(g));
+    float* dst_odd = sI + r0 * LDP + (VEC ? g * 8 + 4 * (1 - ((g >> 2) & 1)) : kpos(g));
     const float* pb = sI + mycol * LDP + 4 * (lane >> 5);
+    const float* pbx = sI + mycol * LDP + 4 * (1 - (lane >> 5));
 
     float pre[G::NPRE];
     float ia_next = -0.0f;
@@ -653,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
             if (kc0 < k) {  // block-uniform
                 const int kcn = (k - kc0 < KC) ? (k - kc0) : KC;
                 __syncthreads();  // every wave is done with the previous chunk in sI
-                if (c == 0 ? live0 : live1) store_chunk<KS, VEC, G::NPRE>(dst, pre);
+                if (c == 0 ? live0 : live1) store_chunk<KS, VEC, G::NPRE>(dst, dst_odd, pre);
                 __syncthreads();
                 // next chunk (this tile's or the next tile's first) -> registers, in flight during the MFMAs
                 if (kc0 + KC < k) {
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
                     prefetch_chunk<KS, VEC, G::NPRE>(pre, a.I, i0 + TI, a.Ni, k, 0, r0, gc0);
                     ia_next = load_iadd(a, i0 + TI + mycol);
                 }
-                mfma_chunk<JPC / 8>(acc, areg + c * (KC / 2), pb, (kcn + 15) >> 4);
+                mfma_chunk<JPC / 8>(acc, areg + c * (KC / 2), pb, pbx, (kcn + 15) >> 4);
             }
         }
         sel_store_scores(z, a, acc, ua, ia, affine, wu, wi, lane);
@@ -799,8 +804,10 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
     const int g = tid % G::CPT, r0 = tid / G::CPT;
     const bool live0 = g * G::W < k;
     const int gc0 = live0 ? g : 0;
-    float* dst = sI + r0 * LDP + (VEC ? g * 8 : kpos(g));
+    float* dst = sI + r0 * LDP + (VEC ? g * 8 + 4 * ((g >> 2) & 1) : kpos(g));
+    float* dst_odd = sI + r0 * LDP + (VEC ? g * 8 + 4 * (1 - ((g >> 2) & 1)) : kpos(g));
     const float* pb = sI + mycol * LDP + 4 * (lane >> 5);
+    const float* pbx = sI + mycol * LDP + 4 * (1 - (lane >> 5));
 
     float pre[G::NPRE];
     float ia_next = -0.0f;
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
         DR_TRACE(1);
         if (tid == 0) misc[1 + ((t + 1) & 1)] = 0;
 #if DR_ABL != 3
-        if (live0) store_chunk<KS, VEC, G::NPRE>(dst, pre);
+        if (live0) store_chunk<KS, VEC, G::NPRE>(dst, dst_odd, pre);
 #endif
         DR_TRACE(2);
         const float ia = ia_next;
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
 #if DR_ABL != 12
         __builtin_amdgcn_s_setprio(0);
 #endif
-        mfma_chunk<KS / 8>(acc, areg, pb, (k + 15) >> 4);
+        mfma_chunk<KS / 8>(acc, areg, pb, pbx, (k + 15) >> 4);
 #if DR_ABL != 12
         __builtin_amdgcn_s_setprio(3);
 #endif
