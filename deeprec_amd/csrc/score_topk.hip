@@ -981,14 +981,16 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
             }
         }
         DR_TRACE(5);
-        bool any = false;
+        // wave-uniform "something to do" mask built from compare results in scalar registers (ballots): written as a
+        // per-lane bool the compiler assembled it with ~60 extra vector instructions per tile
+        unsigned long long any = 0ull;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float sc = acc[r];
             cnt[r] += (sc > stR[r]) ? 1 : 0;
 #if DR_ABL != 1
-            any |= (sc > tauR[r]);        // beats the K-th best (tau = -inf while the list is not full)
-            any |= (sc == stR[r]);        // tie with the held-out item: decided by item id
+            any |= __builtin_amdgcn_ballot_w64(sc > tauR[r]);   // beats the K-th best (tau = -inf: list not full)
+            any |= __builtin_amdgcn_ballot_w64(sc == stR[r]);   // tie with the held-out item: decided by item id
 #endif
         }
         if (any) {                        // rare after the first tiles: only the lanes / entries concerned do anything
