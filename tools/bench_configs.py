@@ -4,7 +4,7 @@
 cases, not bench lines: this tool only records where each one stands (synthetic ids of the right shape, random
 weights; one JSON object on stdout, kept under profiles/).
 
-    python tools/bench_configs.py > profiles/r01_configs.json
+    python tools/bench_configs.py > profiles/r02_configs.json
 """
 import contextlib
 import io
