@@ -103,123 +103,173 @@ __global__ __launch_bounds__(256) void hconv_pool_fwd_kernel(const float* __rest
 // out[b, h, c] = max(0, max_t (bias + sum_{r < h} <e[b, t + r], W[h, c, r]>)) computed where it is needed only:
 // L (L + 1) (L + 2) / 6 row products per (sequence, filter) instead of the L^2 (L + 1) / 2 of G = e W^T (2.9x fewer at
 // L = 50), and nothing round-trips through HBM.  v_mfma_f32_16x16x4_f32 with M = 16 SEQUENCES (so every MFMA row is
-// useful whatever L - h + 1 is), N = 16 filters of one height, K = the window's h d elements.  One wave owns
-// (height h, 16 sequences) and walks the positions in blocks of 8: 8 accumulators; per (row r, 16-column block) ONE
-// new 16-byte operand load per lane for each of e and W feeds 32 MFMAs, because the windows of 8 consecutive
-// positions share all but one slab row per r.  Operands come straight from L2 (W: 10 MB at C5, e: 25 KB per
-// sequence); the four waves of a workgroup share h, so W's rows are in the CU's vector L1 for three of them.
+// useful whatever L - h + 1 is), N = 16 filters of one height, K = the window's h d elements.
+//
+// One workgroup owns 16 sequences and the PAIR of heights (hA, hB = L + 1 - hA): every pair costs the same 2 hA hB row
+// products per column, and its L + 1 positions split evenly over the four waves (hA's extra positions go to the first
+// waves, hB's to the last: 94 % balance over all pairs at L = 50).  The wave keeps the accumulators of its positions
+// (<= 16 of hA, <= 8 of hB) in registers across the whole K loop: for each 16-column chunk cb the workgroup stages
+// e[16 sequences, L rows, 16 columns] (L KB) into LDS with coalesced loads, then each wave runs over the filter rows r:
+// one 16-byte B operand per lane from global memory (the four waves read the same rows: vector-L1 hits, requested four
+// rows ahead) and one ds_read_b128 per (r, position) for A, four MFMAs each.  Measured on the way here (C5 shape): the
+// same MFMA stream with operands taken from L2 by per-lane loads ran at 51 % of the fp32 MFMA peak, 95 % with the loads
+// removed -- 18.7 GB of half-used cache lines and an exposed reload at every (position block, column chunk) start.
 // Lane l: i = l % 16 (sequence as A row / filter as B column), q = l / 16; its float4 holds columns 16 cb + 4 q + j,
 // and MFMA j contracts over q.  D: lane holds (sequence 4 q + v, filter i), v = 0..3.
 typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ int hc_height_of_rank(int rank, int L) {   // descending cost h (L + 1 - h): middle outwards
-    const int mid = (L + 1) / 2;
-    return (rank & 1) ? mid + (rank + 1) / 2 : mid - rank / 2;
-}
-
 #define HC_LD4(p) (*reinterpret_cast<const hc_f32x4*>(p))
+constexpr int HC_NA = 16;   // positions per wave of the pair's lower height (T <= 64)
+constexpr int HC_NB = 8;    // ... of its upper height (T <= 32)
 
-// TT positions t0 .. t0 + TT - 1 of height h for the wave's 16 sequences x 16 filters: best / bt updated.
-// Rows r are taken in groups of 8: the group's 8 filter rows (bcur) and the 8 + 8 slab rows t0 + r0 .. t0 + r0 + 15 its
-// windows touch (a, anew) are in registers, the NEXT group's operands are requested before the group's 32 TT MFMAs.
-template <int TT>
-__device__ __forceinline__ void hc_block(const float* __restrict__ ea, const float* __restrict__ wb, int d, int ncb, int L,
-                                         int h, int t0, float bv, float (&best)[4], int (&bt)[4]) {
-    hc_f32x4 acc[TT];
+// N positions t_start .. t_start + N - 1 of height hh, one column chunk: acc[tt] += sum_r <slab row t + r, filter row r>.
+// slab: the staged chunk + 4 * lane (row s at slab + 256 s); wr: the lane's filter row 0 of this chunk (row r at wr + r d)
+template <int N, int NMAX>
+__device__ __forceinline__ void hc_rows(hc_f32x4 (&acc)[NMAX], const float* __restrict__ slab,
+                                        const float* __restrict__ wr, int d, int hh, int t_start) {
+    hc_f32x4 b[4];
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) acc[tt] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    for (int cb = 0; cb < ncb; ++cb) {
-        const float* ec = ea + cb * 16;
-        const float* wc = wb + cb * 16;
-        hc_f32x4 a[8], bcur[8];
+    for (int u = 0; u < 4; ++u) b[u] = HC_LD4(wr + (int64_t)(u < hh ? u : hh - 1) * d);
+    const float* ap = slab + t_start * 256;
+    for (int r0 = 0; r0 < hh; r0 += 4) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int row = (t0 + k < L) ? t0 + k : L - 1;          // rows / filter rows past the end: clamped, unused
-            a[k] = HC_LD4(ec + (int64_t)row * d);
-            bcur[k] = HC_LD4(wc + (int64_t)(k < h ? k : h - 1) * d);
-        }
-        for (int r0 = 0; r0 < h; r0 += 8) {
-            const int nr = h - r0;
-            hc_f32x4 anew[8], bnext[8];
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u < hh) {
+                const float* ar = ap + (r0 + u) * 256;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int row = (t0 + r0 + 8 + k < L) ? t0 + r0 + 8 + k : L - 1;
-                anew[k] = HC_LD4(ec + (int64_t)row * d);
-                bnext[k] = HC_LD4(wc + (int64_t)(r0 + 8 + k < h ? r0 + 8 + k : h - 1) * d);
-            }
+                for (int t4 = 0; t4 < N; t4 += 4) {
+                    hc_f32x4 a[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (u < nr) {
+                    for (int k = 0; k < 4; ++k)
+                        if (t4 + k < N) a[k] = HC_LD4(ar + (t4 + k) * 256);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int tt = 0; tt < TT; ++tt) {
-                            const float av = (u + tt < 8) ? a[(u + tt) & 7][j] : anew[(u + tt) & 7][j];
-                            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bcur[u][j], acc[tt], 0, 0, 0);
-                        }
+                        for (int k = 0; k < 4; ++k)
+                            if (t4 + k < N)
+                                acc[t4 + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][j], b[u][j], acc[t4 + k], 0, 0, 0);
                 }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                a[k] = anew[k];
-                bcur[k] = bnext[k];
             }
+            const int rn = r0 + u + 4;      // rows past the end: clamped, unused
+            b[u] = HC_LD4(wr + (int64_t)(rn < hh ? rn : hh - 1) * d);
         }
     }
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float val = acc[tt][v] + bv;
-            if (val > best[v]) {
-                best[v] = val;
-                bt[v] = t0 + tt;
+}
+
+template <int NMAX>
+__device__ __forceinline__ void hc_rows_n(int n, hc_f32x4 (&acc)[NMAX], const float* slab, const float* wr, int d, int hh,
+                                          int t_start) {
+    switch (n) {
+#define HC_CASE(N_) case N_: hc_rows<N_, NMAX>(acc, slab, wr, d, hh, t_start); break;
+        HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
+        default:
+            if constexpr (NMAX > 8) {
+                switch (n) {
+                    HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12) HC_CASE(13) HC_CASE(14) HC_CASE(15) HC_CASE(16)
+                    default: break;
+                }
             }
-        }
+            break;
+#undef HC_CASE
+    }
+}
+
+// the wave's best position of one height -> LDS (float best, int position) per (lane, v)
+template <int NMAX>
+__device__ __forceinline__ void hc_wave_best(const hc_f32x4 (&acc)[NMAX], int n, int t_start, float bv, float* bests,
+                                             int* bts, int wave, int lane) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float best = -INFINITY;
+        int bt = 0;
+#pragma unroll
+        for (int tt = 0; tt < NMAX; ++tt)
+            if (tt < n) {
+                const float val = acc[tt][v] + bv;
+                if (val > best) {
+                    best = val;
+                    bt = t_start + tt;
+                }
+            }
+        bests[(wave * 4 + v) * 64 + lane] = best;
+        bts[(wave * 4 + v) * 64 + lane] = bt;
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void hconv_direct_fwd_kernel(const float* __restrict__ e, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, int64_t B, int L, int C,
                                                                   int d, int nsg, float* __restrict__ out,
                                                                   int32_t* __restrict__ arg) {
+    extern __shared__ float lds[];          // [L rows][16 sequences][16 columns]; the epilogue's 16 KB reuse it
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int h = hc_height_of_rank(blockIdx.x / nsg, L);
-    const int64_t s0 = ((int64_t)(blockIdx.x % nsg) * 4 + wave) * 16;
-    if (s0 >= B) return;
-    const int T = L - h + 1, ncb = d / 16;
+    const int npairs = (L + 1) / 2;
+    const int pr = npairs - 1 - (int)(blockIdx.x / nsg);        // costliest pairs (hA ~ hB) first
+    const int hA = pr + 1, hB = L - pr;                         // hA <= hB; equal: the middle height of an odd L, once
+    const int64_t s0 = (int64_t)(blockIdx.x % nsg) * 16;
+    const int TA = L + 1 - hA, TB = (hB != hA) ? L + 1 - hB : 0;
+    const int nA = TA / 4 + (wave < TA % 4 ? 1 : 0);
+    const int tA = wave * (TA / 4) + (wave < TA % 4 ? wave : TA % 4);
+    const int xB = 4 - TB % 4;                                  // waves xB .. 3 take hB's extra positions
+    const int nB = TB / 4 + ((TB % 4) && wave >= xB ? 1 : 0);
+    const int tB = wave * (TB / 4) + ((TB % 4) && wave > xB ? wave - xB : 0);
     const int64_t seq = (s0 + i < B) ? s0 + i : B - 1;
     const int filt = i < C ? i : C - 1;
-    const float* ea = e + seq * L * d + 4 * q;
-    const float* wb = W + (hc_off(C, h) + (int64_t)filt * h) * d + 4 * q;
-    const float bv = bias[(h - 1) * C + filt];
-    float best[4];
-    int bt[4];
+    const float* eg = e + seq * L * d + 4 * q;                                   // + s d + 16 cb
+    const float* wA = W + (hc_off(C, hA) + (int64_t)filt * hA) * d + 4 * q;      // + r d + 16 cb
+    const float* wB = W + (hc_off(C, hB) + (int64_t)filt * hB) * d + 4 * q;
+    hc_f32x4 accA[HC_NA], accB[HC_NB];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        best[v] = -INFINITY;
-        bt[v] = 0;
-    }
-    int t0 = 0;
-    for (; t0 + 8 <= T; t0 += 8) hc_block<8>(ea, wb, d, ncb, L, h, t0, bv, best, bt);
-    switch (T - t0) {
-        case 1: hc_block<1>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
-        case 2: hc_block<2>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
-        case 3: hc_block<3>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
-        case 4: hc_block<4>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
-        case 5: hc_block<5>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
-        case 6: hc_block<6>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
-        case 7: hc_block<7>(ea, wb, d, ncb, L, h, t0, bv, best, bt); break;
-        default: break;
-    }
-    if (i < C) {
+    for (int t = 0; t < HC_NA; ++t) accA[t] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int64_t sq = s0 + 4 * q + v;
-            if (sq < B) {
-                const int64_t o = sq * ((int64_t)C * L) + (h - 1) * C + i;
-                out[o] = best[v] > 0.0f ? best[v] : 0.0f;
-                arg[o] = best[v] > 0.0f ? bt[v] : -1;
+    for (int t = 0; t < HC_NB; ++t) accB[t] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const float* slab = lds + 4 * lane;
+    const int ncb = d / 16;
+    for (int cb = 0; cb < ncb; ++cb) {
+        __syncthreads();                    // the previous chunk's readers are done
+        for (int sb = 0; sb < L; sb += 32) {                    // wave w stages rows w, w + 4, ...: 8 loads in flight
+            hc_f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = sb + 4 * k + wave;
+                v[k] = HC_LD4(eg + (int64_t)(s < L ? s : L - 1) * d + cb * 16);
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = sb + 4 * k + wave;
+                if (s < L) *reinterpret_cast<hc_f32x4*>(lds + s * 256 + 4 * lane) = v[k];
+            }
+        }
+        __syncthreads();
+        hc_rows_n<HC_NA>(nA, accA, slab, wA + cb * 16, d, hA, tA);
+        hc_rows_n<HC_NB>(nB, accB, slab, wB + cb * 16, d, hB, tB);
+    }
+    __syncthreads();
+    float* bests = lds;                                         // [height A / B][wave][v][lane]
+    int* bts = reinterpret_cast<int*>(lds + 2 * 1024);
+    hc_wave_best<HC_NA>(accA, nA, tA, bias[(hA - 1) * C + filt], bests, bts, wave, lane);
+    hc_wave_best<HC_NB>(accB, nB, tB, bias[(hB - 1) * C + filt], bests + 1024, bts + 1024, wave, lane);
+    __syncthreads();
+    // thread (wave, lane) finishes v = wave of both heights: waves in ascending position order, the first maximum wins
+    const int64_t sq = s0 + 4 * q + wave;
+    if (i < C && sq < B) {
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            if (hx == 1 && TB == 0) break;
+            const int hh = hx ? hB : hA;
+            float best = -INFINITY;
+            int bt = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float v = bests[hx * 1024 + (w * 4 + wave) * 64 + lane];
+                if (v > best) {
+                    best = v;
+                    bt = bts[hx * 1024 + (w * 4 + wave) * 64 + lane];
+                }
+            }
+            const int64_t o = sq * ((int64_t)C * L) + (hh - 1) * C + i;
+            out[o] = best > 0.0f ? best : 0.0f;
+            arg[o] = best > 0.0f ? bt : -1;
         }
     }
 }
@@ -456,9 +506,15 @@ extern "C" int32_t dr_caser_hconv_direct_f32(const float* e, const float* W, con
     if (B == 0) return DR_OK;
     DR_REQUIRE(e && W && bias && out && arg && (((uintptr_t)e | (uintptr_t)W) % 16 == 0),
                "dr_caser_hconv_direct_f32: NULL / misaligned pointer");
-    const int64_t nsg = (B + 63) / 64;
-    DR_REQUIRE(nsg * L < (1ll << 31) - 1, "dr_caser_hconv_direct_f32: grid too large");
-    DR_LAUNCH_NAMED("hconv_direct_fwd_kernel", hconv_direct_fwd_kernel, dim3((unsigned)(nsg * L)), dim3(256), 0,
+    const int64_t nsg = (B + 15) / 16;
+    const int npairs = (L + 1) / 2;
+    DR_REQUIRE(nsg * npairs < (1ll << 31) - 1, "dr_caser_hconv_direct_f32: grid too large");
+    size_t lds = (size_t)L * 1024;          // the staged chunk; the epilogue needs 16 KB
+    if (lds < 16 * 1024) lds = 16 * 1024;
+    if (lds > 48 * 1024)
+        DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hconv_direct_fwd_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DR_LAUNCH_NAMED("hconv_direct_fwd_kernel", hconv_direct_fwd_kernel, dim3((unsigned)(nsg * npairs)), dim3(256), lds,
                     (hipStream_t)stream, e, W, bias, B, (int)L, (int)C, (int)d, (int)nsg, out, arg);
     DR_CHECK_LAUNCH("hconv_direct_fwd_kernel");
     return DR_OK;

@@ -489,6 +489,28 @@ def test_score_topk_leave_one_out(dev, Nu, Ni, k, K_, kind):
     _check_selection(scores, [[]] * Nu, [[]] * Nu, K_, N(idx2), N(val2), None)
 
 
+def test_score_topk_leave_one_out_is_repeatable(dev):
+    """Regression for a lost-update race in score_kernel_t1: with one 64-item tile per block every score of the tile is a
+    candidate, and the candidate stores of the rows a lane writes LAST were still in flight at the next barrier (no
+    s_waitcnt on the loop's back edge) -- a few users lost top-K entries, different ones per run.  Eight runs on the
+    shape that showed it must agree with the oracle and with each other."""
+    from deeprec_amd import kernels as K
+    Nu, Ni, k, K_ = 300, 2500, 128, 10
+    rng = np.random.default_rng(Nu * 7 + k)
+    U, I, train, _ = _eval_case(rng, Nu, Ni, k, 40, 0, std=0.3)
+    tp, ti = _csr(train)
+    scores = co.score_matrix(U, I, 0, None, None, 0.2, bias=None)
+    tU, tI, ttp, tti = T(U, dev), T(I, dev), T(tp, dev), T(ti, dev)
+    first = None
+    for _ in range(8):
+        idx, val, _r = K.score_topk(tU, tI, K_, train=(ttp, tti))
+        if first is None:
+            first = (idx, val)
+            _check_selection(scores, train, [[]] * Nu, K_, N(idx), N(val), None)
+        else:
+            assert torch.equal(idx, first[0]) and torch.equal(val, first[1])
+
+
 @pytest.mark.parametrize("kind", [1, 2])
 def test_score_topk_distances(dev, kind):
     """CML (cml.py:151-153) and AttRec/PRME (SeqRecMetrics.py:122-123, alpha=0.2) scores."""
