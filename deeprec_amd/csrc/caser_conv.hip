@@ -119,51 +119,73 @@ __global__ __launch_bounds__(256) void hconv_pool_fwd_kernel(const float* __rest
 typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
 
 #define HC_LD4(p) (*reinterpret_cast<const hc_f32x4*>(p))
+#ifndef HC_ABL
+#define HC_ABL 0   // timing ablations (dev; results wrong by construction): 1 no staging, 2 no filter-row loads, 3 no staging +
+                   // no barriers, 4 no LDS reads, 5 staging reads 16 hot sequences, 6 one workgroup per CU, 7 staging
+                   // without the LDS stores, 8 without the global loads
+#endif
 constexpr int HC_NA = 16;   // positions per wave of the pair's lower height (T <= 64)
 constexpr int HC_NB = 8;    // ... of its upper height (T <= 32)
+// one accumulator file for both heights: the lower height's positions fill it from the front, the upper height's from
+// the back; a wave holds at most (T_A + 3) / 4 + (T_B + 3) / 4 <= (L + 1) / 4 + 2 <= 18 positions
+constexpr int HC_NACC = 18;
 
-// N positions t_start .. t_start + N - 1 of height hh, one column chunk: acc[tt] += sum_r <slab row t + r, filter row r>.
-// slab: the staged chunk + 4 * lane (row s at slab + 256 s); wr: the lane's filter row 0 of this chunk (row r at wr + r d)
-template <int N, int NMAX>
-__device__ __forceinline__ void hc_rows(hc_f32x4 (&acc)[NMAX], const float* __restrict__ slab,
+// N positions t_start .. t_start + N - 1 of height hh, one column chunk: acc[..] += sum_r <slab row t + r, filter row r>.
+// slab: the staged chunk + 4 * lane (row s at slab + 256 s); wr: the lane's filter row 0 of this chunk (row r at wr + r d).
+// Position tt accumulates in acc[tt] (DIR = 1) or acc[HC_NACC - 1 - tt] (DIR = -1).  The positions go in NQ groups of
+// <= 4, as even as possible: a lone position would make its four MFMAs a dependent chain.  (Requesting a group's A
+// operands one group ahead from two register buffers, with the scheduler fenced, cost 66 registers and gained 1 %.)
+template <int N, int DIR>
+__device__ __forceinline__ void hc_rows(hc_f32x4 (&acc)[HC_NACC], const float* __restrict__ slab,
                                         const float* __restrict__ wr, int d, int hh, int t_start) {
-    hc_f32x4 b[4];
+    constexpr int NQ = (N + 3) / 4, QB = N / NQ, QX = N % NQ;   // group x: QB + (x < QX) positions from x QB + min(x, QX)
+    constexpr int RD = 4;                   // filter rows in flight (8 for waves with few positions: no faster)
+    hc_f32x4 b[RD];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = HC_LD4(wr + (int64_t)(u < hh ? u : hh - 1) * d);
+    for (int u = 0; u < RD; ++u) b[u] = HC_LD4(wr + (int64_t)(u < hh ? u : hh - 1) * d);
     const float* ap = slab + t_start * 256;
-    for (int r0 = 0; r0 < hh; r0 += 4) {
+    for (int r0 = 0; r0 < hh; r0 += RD) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RD; ++u) {
             if (r0 + u < hh) {
                 const float* ar = ap + (r0 + u) * 256;
 #pragma unroll
-                for (int t4 = 0; t4 < N; t4 += 4) {
+                for (int x = 0; x < NQ; ++x) {
+                    const int sz = QB + (x < QX ? 1 : 0), st = x * QB + (x < QX ? x : QX);
                     hc_f32x4 a[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (t4 + k < N) a[k] = HC_LD4(ar + (t4 + k) * 256);
+#if HC_ABL == 4
+                        if (k < sz) a[k] = b[(u + k) % RD];
+#else
+                        if (k < sz) a[k] = HC_LD4(ar + (st + k) * 256);
+#endif
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (t4 + k < N)
-                                acc[t4 + k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][j], b[u][j], acc[t4 + k], 0, 0, 0);
+                            if (k < sz) {
+                                hc_f32x4& c = acc[DIR > 0 ? st + k : HC_NACC - 1 - st - k];
+                                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][j], b[u][j], c, 0, 0, 0);
+                            }
                 }
             }
-            const int rn = r0 + u + 4;      // rows past the end: clamped, unused
+            const int rn = r0 + u + RD;     // rows past the end: clamped, unused
+#if HC_ABL != 2
             b[u] = HC_LD4(wr + (int64_t)(rn < hh ? rn : hh - 1) * d);
+#endif
         }
     }
 }
 
-template <int NMAX>
-__device__ __forceinline__ void hc_rows_n(int n, hc_f32x4 (&acc)[NMAX], const float* slab, const float* wr, int d, int hh,
-                                          int t_start) {
+template <int DIR>
+__device__ __forceinline__ void hc_rows_n(int n, hc_f32x4 (&acc)[HC_NACC], const float* slab, const float* wr, int d,
+                                          int hh, int t_start) {
     switch (n) {
-#define HC_CASE(N_) case N_: hc_rows<N_, NMAX>(acc, slab, wr, d, hh, t_start); break;
+#define HC_CASE(N_) case N_: hc_rows<N_, DIR>(acc, slab, wr, d, hh, t_start); break;
         HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
         default:
-            if constexpr (NMAX > 8) {
+            if constexpr (DIR > 0) {        // the lower height of a pair: up to 16 positions per wave
                 switch (n) {
                     HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12) HC_CASE(13) HC_CASE(14) HC_CASE(15) HC_CASE(16)
                     default: break;
@@ -175,8 +197,8 @@ __device__ __forceinline__ void hc_rows_n(int n, hc_f32x4 (&acc)[NMAX], const fl
 }
 
 // the wave's best position of one height -> LDS (float best, int position) per (lane, v)
-template <int NMAX>
-__device__ __forceinline__ void hc_wave_best(const hc_f32x4 (&acc)[NMAX], int n, int t_start, float bv, float* bests,
+template <int DIR, int NMAX>
+__device__ __forceinline__ void hc_wave_best(const hc_f32x4 (&acc)[HC_NACC], int n, int t_start, float bv, float* bests,
                                              int* bts, int wave, int lane) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -185,7 +207,7 @@ __device__ __forceinline__ void hc_wave_best(const hc_f32x4 (&acc)[NMAX], int n,
 #pragma unroll
         for (int tt = 0; tt < NMAX; ++tt)
             if (tt < n) {
-                const float val = acc[tt][v] + bv;
+                const float val = acc[DIR > 0 ? tt : HC_NACC - 1 - tt][v] + bv;
                 if (val > best) {
                     best = val;
                     bt = t_start + tt;
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void hconv_direct_fwd_kernel(const float* _
                                                                   int d, int nsg, float* __restrict__ out,
                                                                   int32_t* __restrict__ arg) {
     extern __shared__ float lds[];          // [L rows][16 sequences][16 columns]; the epilogue's 16 KB reuse it
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
     const int npairs = (L + 1) / 2;
     const int pr = npairs - 1 - (int)(blockIdx.x / nsg);        // costliest pairs (hA ~ hB) first
@@ -215,40 +237,54 @@ __global__ __launch_bounds__(256, 2) void hconv_direct_fwd_kernel(const float* _
     const int tB = wave * (TB / 4) + ((TB % 4) && wave > xB ? wave - xB : 0);
     const int64_t seq = (s0 + i < B) ? s0 + i : B - 1;
     const int filt = i < C ? i : C - 1;
-    const float* eg = e + seq * L * d + 4 * q;                                   // + s d + 16 cb
+    const float* eg = e + (HC_ABL == 5 ? (int64_t)i : seq) * L * d + 4 * q;                                   // + s d + 16 cb
     const float* wA = W + (hc_off(C, hA) + (int64_t)filt * hA) * d + 4 * q;      // + r d + 16 cb
     const float* wB = W + (hc_off(C, hB) + (int64_t)filt * hB) * d + 4 * q;
-    hc_f32x4 accA[HC_NA], accB[HC_NB];
+    hc_f32x4 acc[HC_NACC];
 #pragma unroll
-    for (int t = 0; t < HC_NA; ++t) accA[t] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int t = 0; t < HC_NB; ++t) accB[t] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < HC_NACC; ++t) acc[t] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const float* slab = lds + 4 * lane;
     const int ncb = d / 16;
     for (int cb = 0; cb < ncb; ++cb) {
-        __syncthreads();                    // the previous chunk's readers are done
-        for (int sb = 0; sb < L; sb += 32) {                    // wave w stages rows w, w + 4, ...: 8 loads in flight
-            hc_f32x4 v[8];
+#ifndef HC_SB
+#define HC_SB 16
+#endif
+        // wave w stages rows w, w + 4, ...: the loads of a batch of HC_SB rows in flight before the barrier / the stores
+        for (int sb = 0; sb < ((HC_ABL == 1 || HC_ABL == 3) ? 0 : L); sb += 4 * HC_SB) {
+            hc_f32x4 v[HC_SB];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < HC_SB; ++k) {
                 const int s = sb + 4 * k + wave;
+#if HC_ABL == 8
+                v[k] = (hc_f32x4){0.01f * s, 0.02f * lane, 0.03f * cb, 0.5f};
+#else
                 v[k] = HC_LD4(eg + (int64_t)(s < L ? s : L - 1) * d + cb * 16);
+#endif
             }
+#if HC_ABL != 3
+            if (sb == 0) __syncthreads();   // the previous chunk's readers are done
+#endif
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < HC_SB; ++k) {
                 const int s = sb + 4 * k + wave;
+#if HC_ABL == 7
+                if (s < L && v[k][0] == 123.456f) *reinterpret_cast<hc_f32x4*>(lds + s * 256 + 4 * lane) = v[k];
+#else
                 if (s < L) *reinterpret_cast<hc_f32x4*>(lds + s * 256 + 4 * lane) = v[k];
+#endif
             }
         }
+#if HC_ABL != 3
         __syncthreads();
-        hc_rows_n<HC_NA>(nA, accA, slab, wA + cb * 16, d, hA, tA);
-        hc_rows_n<HC_NB>(nB, accB, slab, wB + cb * 16, d, hB, tB);
+#endif
+        hc_rows_n<1>(nA, acc, slab, wA + cb * 16, d, hA, tA);
+        hc_rows_n<-1>(nB, acc, slab, wB + cb * 16, d, hB, tB);
     }
     __syncthreads();
     float* bests = lds;                                         // [height A / B][wave][v][lane]
     int* bts = reinterpret_cast<int*>(lds + 2 * 1024);
-    hc_wave_best<HC_NA>(accA, nA, tA, bias[(hA - 1) * C + filt], bests, bts, wave, lane);
-    hc_wave_best<HC_NB>(accB, nB, tB, bias[(hB - 1) * C + filt], bests + 1024, bts + 1024, wave, lane);
+    hc_wave_best<1, HC_NA>(acc, nA, tA, bias[(hA - 1) * C + filt], bests, bts, wave, lane);
+    hc_wave_best<-1, HC_NB>(acc, nB, tB, bias[(hB - 1) * C + filt], bests + 1024, bts + 1024, wave, lane);
     __syncthreads();
     // thread (wave, lane) finishes v = wave of both heights: waves in ascending position order, the first maximum wins
     const int64_t sq = s0 + 4 * q + wave;
@@ -511,6 +547,9 @@ extern "C" int32_t dr_caser_hconv_direct_f32(const float* e, const float* W, con
     DR_REQUIRE(nsg * npairs < (1ll << 31) - 1, "dr_caser_hconv_direct_f32: grid too large");
     size_t lds = (size_t)L * 1024;          // the staged chunk; the epilogue needs 16 KB
     if (lds < 16 * 1024) lds = 16 * 1024;
+#if HC_ABL == 6
+    lds = 100 * 1024;                       // one workgroup per CU
+#endif
     if (lds > 48 * 1024)
         DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hconv_direct_fwd_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

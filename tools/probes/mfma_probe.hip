@@ -14,6 +14,10 @@ __global__ __launch_bounds__(256) void k16(float* out, int iters, float a0, floa
     float a[8], b[4];
     for (int i = 0; i < 8; ++i) a[i] = a0 + threadIdx.x + i;
     for (int i = 0; i < 4; ++i) b[i] = b0 + i;
+    if (a0 != 1.0f) {   // "real" data: full-mantissa values in [-1, 1)
+        for (int i = 0; i < 8; ++i) a[i] = (float)((threadIdx.x * 2654435761u + i * 40503u + blockIdx.x * 7919u) & 0xffffff) / 8388608.0f - 1.0f;
+        for (int i = 0; i < 4; ++i) b[i] = (float)((threadIdx.x * 2246822519u + i * 3266489917u) & 0xffffff) / 8388608.0f * 0.01f - 0.005f;
+    }
     float m[8];
     for (int i = 0; i < 8; ++i) m[i] = a0 * i;
     for (int it = 0; it < iters; ++it) {
@@ -81,6 +85,15 @@ int main() {
     float* out;
     hipMalloc(&out, 4096);
     const int iters = 2000;
+    for (int real = 0; real < 2; ++real) {
+        const float av = real ? 0.5f : 1.0f;
+        hipFuncSetAttribute((const void*)k16<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        run(real ? "16x16x4 acc=8 REAL data, 2 blocks/CU" : "16x16x4 acc=8 trivial data, 2 blocks/CU",
+            [&](int b, int it) { hipLaunchKernelGGL((k16<8, 0>), dim3(b), dim3(256), 60 * 1024, 0, out, it, av, 2.0f); }, 256.0 * 2048, 2048, iters);
+        run(real ? "16x16x4 acc=8 REAL data, 2 blocks/CU (again)" : "16x16x4 acc=8 trivial data, 2 blocks/CU (again)",
+            [&](int b, int it) { hipLaunchKernelGGL((k16<8, 0>), dim3(b), dim3(256), 60 * 1024, 0, out, it, av, 2.0f); }, 256.0 * 2048, 2048, iters * 4);
+    }
+    return 0;
     const double f16 = 256.0 * 2048, f32 = 128.0 * 4096;
     for (int occ = 1; occ <= 2; ++occ) {
         const size_t lds = occ == 1 ? 100 * 1024 : 60 * 1024;
