@@ -76,6 +76,7 @@ SIGNATURES = {
     "dr_bpr_item_grads_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _p]),
     "dr_mlp_forward_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "dr_mlp_backward_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "dr_tower_catalog_scores_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p]),
     "dr_attn_pool_forward_f32": (_i32, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "dr_attn_pool_backward_f32": (_i32, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "dr_caser_vconv_forward_f32": (_i32, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p]),

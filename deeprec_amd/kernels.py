@@ -576,6 +576,39 @@ def mlp_backward(x, Ws, acts_kinds, acts, gout, want_gx=True, want_gb=True):
     return gx, gW, gb
 
 
+# 16-wide tile counts (first width, then the four layers) dr_tower_catalog_scores_f32 is instantiated for
+TOWER_SHAPES = {(8, 5, 3, 2, 1), (4, 5, 3, 2, 1), (2, 3, 2, 1, 1)}
+
+
+def tower_catalog_supported(dims):
+    """dims = [h1, n2, n3, n4, n5]: does dr_tower_catalog_scores_f32 have this tower?"""
+    return (len(dims) == 5 and dims[0] % 16 == 0 and all(1 <= d <= 128 for d in dims)
+            and tuple((d + 15) // 16 for d in dims) in TOWER_SHAPES)
+
+
+def tower_catalog_scores(uh, ih, Ws, bs, out):
+    """NeuMF's tower for every (user, item) pair (neumf.py:80-115): out[u, i] += sum relu-tower(relu(uh[u] + ih[i])).
+    uh [nu, h1], ih [ni, h1]: the two halves of the first dense layer (bias in uh); Ws / bs: the remaining four
+    layers; out [nu, ni] float32 (row stride >= ni) arrives holding the GMF dot and is updated in place."""
+    uh = _req(uh, torch.float32, "uh", 2)
+    ih = _req(ih, torch.float32, "ih", 2)
+    if len(Ws) != 4 or len(bs) != 4:
+        raise ValueError("tower_catalog_scores: four layers after the split first one")
+    Ws = [_req(W, torch.float32, "W", 2) for W in Ws]
+    bs = [_req(b, torch.float32, "b", 1) for b in bs]
+    dims = [uh.shape[1]] + [W.shape[1] for W in Ws]
+    if ih.shape[1] != dims[0] or any(W.shape[0] != dims[l] or bs[l].shape[0] != dims[l + 1] for l, W in enumerate(Ws)):
+        raise ValueError("tower_catalog_scores: layer shapes do not chain")
+    if out.dtype != torch.float32 or out.dim() != 2 or tuple(out.shape) != (uh.shape[0], ih.shape[0]) or out.stride(1) != 1:
+        raise ValueError("tower_catalog_scores: out must be float32 [nu, ni] with unit column stride")
+    _on_current_device(out, "out")
+    ptrs = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    check(_abi.lib().dr_tower_catalog_scores_f32(_ptr(uh), uh.shape[0], _ptr(ih), ih.shape[0], (C.c_int32 * 5)(*dims),
+                                                 ptrs(Ws), ptrs(bs), _ptr(out), out.stride(0), _stream()),
+          "dr_tower_catalog_scores_f32")
+    return out
+
+
 # ------------------------------------------------------------------ AttRec self-attention pooling
 ATT_MAX_L, ATT_MAX_D = 64, 256
 

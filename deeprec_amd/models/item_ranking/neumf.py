@@ -5,8 +5,8 @@ concat[mlp_q, mlp_p] 128->128->80->40->20->10, ReLU everywhere, N(0,1) kernels, 
 yhat = sigmoid(sum concat[GMF, MLP]); BCE(+1e-10) + kernel reg + reg*(l2 of the four tables); Adagrad(0.5).
 
 Lookups, their duplicate-summing backward and every optimizer application run on the HIP kernels; the MLP's
-small GEMMs (<= 128x128) are torch matmuls (rocBLAS) under autograd.  Evaluation scores the whole catalog per
-user chunk on the device and selects with dr_topk_rank_f32 (the score is not a bilinear form).
+small GEMMs (<= 128x128) are torch matmuls (rocBLAS) under autograd.  Evaluation runs the tower for every (user, item)
+pair of a user chunk in dr_tower_catalog_scores_f32 and selects with dr_topk_rank_f32 (the score is not a bilinear form).
 """
 import random
 import time
@@ -166,22 +166,42 @@ class NeuMF(object):
         with torch.no_grad():
             return torch.sigmoid(self._logit(u, i)).cpu().numpy()
 
-    def eval_scores(self, users, chunk=128):
-        """sigmoid scores [len(users), num_item] for the evaluator (first MLP layer split into its item and user
-        halves so the item half is computed once)."""
+    def eval_score_chunks(self, users, chunk=None):
+        """Yields (c0, c1, sigmoid scores [c1 - c0, num_item]) for consecutive chunks of `users` -- the evaluator selects
+        per chunk, so neither the [users, items] matrix nor any per-pair activation exists in HBM.  The first dense layer
+        is linear in concat[mlp_q, mlp_p]: its item half is computed once, its user half per chunk (two small GEMMs);
+        the rest of the tower runs for every pair inside dr_tower_catalog_scores_f32 (MFMA, activations in registers)
+        on top of the GMF dots from dr_score_matrix_f32.  Tower shapes the kernel is not instantiated for take the
+        library-GEMM path below (128 users at a time)."""
         users = list(users)
-        out = torch.empty((len(users), self.num_item), dtype=torch.float32, device=self.device)
+        dims = [k.shape[1] for k in self.kernels]
+        fused = len(self.kernels) == 5 and K.tower_catalog_supported(dims)
+        if chunk is None:
+            chunk = max(1, min(len(users), (1 << 26) // max(1, self.num_item))) if fused else 128
         with torch.no_grad():
             W0 = self.kernels[0]
             km = self.mlp_Q.w.shape[1]
-            item_half = self.mlp_Q.w @ W0[:km]                                   # [Ni, 128]
+            item_half = (self.mlp_Q.w @ W0[:km]).contiguous()                    # [Ni, 128]
             for c0 in range(0, len(users), chunk):
                 u = to_dev(np.asarray(users[c0:c0 + chunk]), torch.int32, self.device)
-                gmf = K.score_matrix(K.gather(self.P.w, u), self.Q.w)            # sum_k p*q for all pairs (MFMA)
-                h = torch.relu(item_half[None] + (K.gather(self.mlp_P.w, u) @ W0[km:])[:, None] + self.biases[0])
-                for W, b in zip(self.kernels[1:], self.biases[1:]):
-                    h = torch.relu(h @ W + b)
-                out[c0:c0 + len(u)] = torch.sigmoid(gmf + h.sum(2))
+                out = K.score_matrix(K.gather(self.P.w, u), self.Q.w)            # sum_k p*q for all pairs (MFMA)
+                user_half = K.gather(self.mlp_P.w, u) @ W0[km:] + self.biases[0]
+                if fused:
+                    K.tower_catalog_scores(user_half.contiguous(), item_half, [w.detach() for w in self.kernels[1:]],
+                                           [b.detach() for b in self.biases[1:]], out)
+                else:
+                    h = torch.relu(item_half[None] + user_half[:, None])
+                    for W, b in zip(self.kernels[1:], self.biases[1:]):
+                        h = torch.relu(h @ W + b)
+                    out += h.sum(2)
+                yield c0, c0 + len(u), torch.sigmoid_(out)
+
+    def eval_scores(self, users, chunk=None):
+        """sigmoid scores [len(users), num_item] in one tensor (tests, small catalogs)."""
+        users = list(users)
+        out = torch.empty((len(users), self.num_item), dtype=torch.float32, device=self.device)
+        for c0, c1, sc in self.eval_score_chunks(users, chunk):
+            out[c0:c1] = sc
         return out
 
     def eval_train_items(self, u):

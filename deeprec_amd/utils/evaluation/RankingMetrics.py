@@ -6,6 +6,8 @@ model.neg_items[u], model.test_data[u], calls model.predict) but replaces the pe
 predict + Python sort by one full-catalog scoring + masked top-K + rank-of-target launch:
   * models that expose `eval_operands()` (bilinear / distance scores) -> dr_score_topk_f32 (MFMA GEMM, scores
     never reach HBM);
+  * models that expose `eval_score_chunks()` (NeuMF's tower) -> dr_tower_catalog_scores_f32 per user chunk,
+    selection by dr_topk_rank_f32 per chunk;
   * any other model -> model.predict over each user's candidates, selection by dr_topk_rank_f32.
 It prints what the reference prints and additionally RETURNS the dict of the nine means.
 """
@@ -54,6 +56,15 @@ def rank_targets(model, users, K=10):
             rank = Kn.score_rank_exact(ops["U"], ops["I"], (gp, gi), score_kind=ops.get("kind", Kn.SCORE_DOT),
                                        U2=ops.get("U2"), I2=ops.get("I2"), w1=np.float32(a), w2=np.float32(1 - a),
                                        item_bias=ops.get("item_bias"), train=(tp, ti))
+    elif hasattr(model, "eval_score_chunks"):
+        # scores that are no bilinear form (NeuMF's tower): the model yields [chunk, num_item] score blocks, the
+        # selection runs per block -- the full [users, items] matrix never exists
+        idxs, ranks = [], []
+        for c0, c1, scores in model.eval_score_chunks(users):
+            i_, _, r_ = Kn.topk_rank(scores, K, train=pack_csr(masked[c0:c1], dev), targets=pack_csr(tgt[c0:c1], dev))
+            idxs.append(i_)
+            ranks.append(r_)
+        idx, rank = torch.cat(idxs), torch.cat(ranks)
     elif hasattr(model, "eval_scores"):
         idx, _, rank = Kn.topk_rank(model.eval_scores(users), K, train=(tp, ti), targets=(gp, gi))
     else:

@@ -358,6 +358,19 @@ int32_t dr_mlp_backward_f32(const float* x, int64_t B, int32_t L, const int32_t*
                             const float* const* W, const float* acts, const float* gout, float* deltas, float* gx,
                             float* const* gW, float* const* gb, void* stream);
 
+/* ---- full-catalog scores of NeuMF's pairwise tower (reference models/item_ranking/neumf.py:80-115 evaluated
+ * for every (user, item) pair by utils/evaluation/RankingMetrics.py:82-101 through predict, neumf.py:213-214) -------
+ * The first dense layer is linear in concat[item, user] and is passed split: uh [nu, dims[0]] = mlp_P[u] W0[user rows]
+ * + b0, ih [ni, dims[0]] = mlp_Q W0[item rows] (two small GEMMs of the caller).  For every pair:
+ *   h1 = relu(uh[u] + ih[i]);  h_{l+1} = relu(h_l W[l] + b[l]), W[l] [dims[l], dims[l+1]] row-major, l = 0..3;
+ *   out[u * ldo + i] += sum_n h5[n]          (out arrives holding the other summand of the logit: the GMF dot <P[u], Q[i]>)
+ * One MFMA kernel, activations never leave registers; fp32, fixed summation order (features ascending in groups of 4).
+ * dims / W / b are HOST arrays (5 ints, 4 + 4 device pointers); dims[0] % 16 == 0, every width <= 128; shapes are
+ * instantiated per 16-wide tile counts (the reference's defaults 128-80-40-20-10 and a few others), anything else is
+ * refused with DR_ERR_ARG. */
+int32_t dr_tower_catalog_scores_f32(const float* uh, int64_t nu, const float* ih, int64_t ni, const int32_t* dims,
+                                    const float* const* W, const float* const* b, float* out, int64_t ldo, void* stream);
+
 /* ---- AttRec self-attention pooling (reference models/seq_rec/AttRec.py:147-186) ----------------
  * pre [B, L, d] = (Q[item_seq] + timing signal) W, the pre-activation of the shared "linear_project" layer
  * (AttRec.py:150-160; the projection itself stays a library GEMM); v [B, L, d] = Q[item_seq] (AttRec.py:142).

@@ -441,6 +441,25 @@ def caser_hconv_forward(e, filters, biases, dtype=f32):
 
 
 # --------------------------------------------------------------------------
+# NeuMF's logit for every (user, item) pair   (neumf.py:73-115; evaluated over the whole catalog through predict,
+# neumf.py:213-214, by RankingMetrics.py:82-101)
+# --------------------------------------------------------------------------
+def neumf_catalog_logits(P, Q, mlp_P, mlp_Q, Ws, bs, users, dtype=np.float64):
+    """logit[r, i] = sum(P[u] * Q[i]) + sum(MLP(concat[mlp_Q[i], mlp_P[u]])) for u = users[r] and every item i; the
+    reference applies tf.sigmoid to it (neumf.py:115).  ReLU after every dense layer (neumf.py:80-113)."""
+    P, Q, mlp_P, mlp_Q = (np.asarray(a, dtype) for a in (P, Q, mlp_P, mlp_Q))
+    Ws = [np.asarray(w, dtype) for w in Ws]
+    bs = [np.asarray(b, dtype) for b in bs]
+    out = np.empty((len(users), Q.shape[0]), dtype)
+    for r, u in enumerate(users):
+        x = np.concatenate((mlp_Q, np.broadcast_to(mlp_P[u], mlp_Q.shape)), 1)      # neumf.py:81
+        for W, b in zip(Ws, bs):
+            x = np.maximum(x @ W + b, 0)
+        out[r] = (P[u] * Q).sum(1) + x.sum(1)                                         # neumf.py:78, 115
+    return out
+
+
+# --------------------------------------------------------------------------
 # K6  full-catalog scoring, masked top-K, rank-of-target
 #     (RankingMetrics.py:82-101, SeqRecMetrics.py:122-123,155,213,234)
 # --------------------------------------------------------------------------

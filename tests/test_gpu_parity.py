@@ -878,6 +878,55 @@ def test_mlp_forward_backward(dev, B, dims, kinds):
     assert torch.equal(acts, acts2) and torch.equal(gx, gx2) and all(torch.equal(a, b) for a, b in zip(gW, gW2))
 
 
+@pytest.mark.parametrize("nu,ni,dims", [(5, 3706, [128, 80, 40, 20, 10]), (3, 70, [128, 80, 40, 20, 10]),
+                                        (17, 1, [64, 80, 40, 20, 10]), (2, 129, [32, 40, 20, 10, 5]),
+                                        (300, 64, [128, 72, 33, 20, 3])])
+def test_tower_catalog_scores(dev, nu, ni, dims):
+    """dr_tower_catalog_scores_f32 (NeuMF's tower for every (user, item) pair, neumf.py:80-115) against the float64
+    restatement oracle.neumf_catalog_logits: 1e-5 of the logits' scale (north_star's fp32 bar; fp32 MFMA sums vs float64);
+    the additive input (the GMF dot) is kept; two runs bit-identical; widths that are no multiple of 16 are padded."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(nu * 7 + ni)
+    m = dims[0] // 2
+    mlp_P = rng.standard_normal((nu, m)).astype(np.float32)
+    mlp_Q = rng.standard_normal((ni, m)).astype(np.float32)
+    P = rng.standard_normal((nu, 10)).astype(np.float32)
+    Q = rng.standard_normal((ni, 10)).astype(np.float32)
+    full = [2 * m] + dims
+    Ws = [(rng.standard_normal((full[l], full[l + 1])) / np.sqrt(full[l])).astype(np.float32) for l in range(5)]
+    bs = [(rng.standard_normal(full[l + 1]) * 0.1).astype(np.float32) for l in range(5)]
+    want = ro.neumf_catalog_logits(P, Q, mlp_P, mlp_Q, Ws, bs, list(range(nu)))
+    # the split first layer, in float64 on the host so that the test isolates the kernel
+    ih = (mlp_Q.astype(np.float64) @ Ws[0][:m].astype(np.float64)).astype(np.float32)
+    uh = (mlp_P.astype(np.float64) @ Ws[0][m:].astype(np.float64) + bs[0]).astype(np.float32)
+    base = (P.astype(np.float64) @ Q.astype(np.float64).T).astype(np.float32)
+    # the restatement on the SAME rounded halves (the rounding of ih / uh to fp32 is the caller's, not the kernel's)
+    h = np.maximum(uh[:, None, :].astype(np.float64) + ih[None].astype(np.float64), 0)
+    for W, b in zip(Ws[1:], bs[1:]):
+        h = np.maximum(h @ W.astype(np.float64) + b, 0)
+    want_same = base.astype(np.float64) + h.sum(2)
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(want_same, want, rtol=0, atol=2e-6 * scale)      # the split is the same function
+    out = T(base.copy(), dev)
+    K.tower_catalog_scores(T(uh, dev), T(ih, dev), [T(w, dev) for w in Ws[1:]], [T(b, dev) for b in bs[1:]], out)
+    np.testing.assert_allclose(N(out), want_same, rtol=0, atol=1e-5 * scale)
+    out2 = T(base.copy(), dev)
+    K.tower_catalog_scores(T(uh, dev), T(ih, dev), [T(w, dev) for w in Ws[1:]], [T(b, dev) for b in bs[1:]], out2)
+    assert torch.equal(out, out2)
+
+
+def test_tower_catalog_scores_refuses_unknown_shapes(dev):
+    from deeprec_amd import kernels as K
+    from deeprec_amd._abi import DeepRecError
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    with pytest.raises(DeepRecError, match="no instantiation"):
+        K.tower_catalog_scores(z(2, 128), z(3, 128), [z(128, 128), z(128, 64), z(64, 32), z(32, 16)],
+                               [z(128), z(64), z(32), z(16)], z(2, 3))
+    with pytest.raises(ValueError):
+        K.tower_catalog_scores(z(2, 128), z(3, 64), [z(128, 80), z(80, 40), z(40, 20), z(20, 10)],
+                               [z(80), z(40), z(20), z(10)], z(2, 3))
+
+
 # ------------------------------------------------------------------ AttRec self-attention pooling
 @pytest.mark.parametrize("B,L,d", [(3, 5, 16), (7, 50, 128), (2, 64, 256), (5, 3, 150), (4, 1, 7), (9, 50, 150),
                                    (1100, 6, 30)])
