@@ -4,6 +4,8 @@ ctypes -> libdeeprec_amd.so), against the CPU oracle on the same seeded inputs.
 Bars (BASELINE.json north_star): gathered rows, scatter-add sums and top-K indices bit-exact;
 losses / scores / updated rows within 1e-5 relative (fp32).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
