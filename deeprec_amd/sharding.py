@@ -131,6 +131,10 @@ class ShardedBpr:
 
     # ---- ids only --------------------------------------------------------------------------------------
     def route(self, u, i, j):
+        return self._route_finish(self._route_begin(u, i, j))
+
+    def _route_begin(self, u, i, j):
+        """The part of a route that needs no host synchronisation: the id all-gather and dr_route_views_i32."""
         ops, W = self.ops, self.world
         P, Q = self.P, self.Q
         B = u.numel()
@@ -144,7 +148,13 @@ class ShardedBpr:
             _gather_ids(ids, mine, self.route_group)               # the one collective of a route
         else:
             ids = mine.reshape(1, 3, B)
-        rv = ops.route_views(ids, self.rank, P.rows, Q.rows, self.rpo)
+        return ids, ops.route_views(ids, self.rank, P.rows, Q.rows, self.rpo)
+
+    def _route_finish(self, begun):
+        """The host synchronisation of a route (split sizes) and the owners' segment plans."""
+        ops, W = self.ops, self.world
+        P, Q = self.P, self.Q
+        ids, rv = begun
         c = rv.counts.tolist()                                     # the one host synchronisation of a route
         # the ids are replicated, so every rank sees the same count: a bad batch on ONE rank is refused by ALL ranks
         # here, before any of them enters a row exchange
@@ -201,37 +211,49 @@ class ShardedBpr:
         return torch.zeros(1, dtype=torch.float32, device=dev)
 
     # ---- one batch ahead -------------------------------------------------------------------------------
-    def prefetch(self, u, i, j):
-        """Route a batch now (on the side stream when pipelined); step() consumes it.  The side stream first waits for
+    def _begin_ahead(self, u, i, j):
+        """Enqueue the sync-free part of a route (on the side stream when pipelined).  The side stream first waits for
         an event recorded HERE on the caller's current stream, so ids produced by earlier work on that stream are
         complete before the route reads them -- and nothing enqueued on it later delays the route."""
         if self.side is None:
-            self._pending = self.route(u, i, j)
-            return
+            return self._route_begin(u, i, j)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         self.side.wait_event(ready)
         for t in (u, i, j):
             t.record_stream(self.side)              # the caller may drop the batch right after step()
         with torch.cuda.stream(self.side):
-            rt = self.route(u, i, j)
+            return self._route_begin(u, i, j)
+
+    def _finish_ahead(self, begun):
+        if self.side is None:
+            return self._route_finish(begun)
+        with torch.cuda.stream(self.side):
+            rt = self._route_finish(begun)
             rt.ready = torch.cuda.Event()
             rt.ready.record(self.side)
-        self._pending = rt
+        return rt
+
+    def prefetch(self, u, i, j):
+        """Route a batch now (on the side stream when pipelined); step() consumes it."""
+        self._pending = self._finish_ahead(self._begin_ahead(u, i, j))
 
     def step(self, opt, next_batch=None):
-        """Run the prefetched batch; `next_batch` = (u, i, j) is routed meanwhile.  The route of next_batch is enqueued
-        BEFORE this batch's kernels: its side-stream work waits only for what the caller's stream held at that moment
-        (the previous step), so it overlaps this step's kernels, and its host synchronisation waits for id kernels only."""
+        """Run the prefetched batch; `next_batch` = (u, i, j) is routed meanwhile.  Order on the host: (1) the sync-free
+        part of next_batch's route goes to the side stream, where it waits only for what the caller's stream held at
+        that moment (the previous step); (2) this batch's kernels and exchanges are enqueued; (3) only then the host
+        waits for the route's split sizes -- the id kernels have run beside (2) -- and enqueues the owners' plans.
+        With (3) before (2), as in the first version, the GPU's main stream sat idle through every route's host wait."""
         rt = self._pending
         if rt is None:
             raise RuntimeError("ShardedBpr.step: no routed batch (call prefetch first)")
         self._pending = None
-        if next_batch is not None:
-            self.prefetch(*next_batch)
+        begun = self._begin_ahead(*next_batch) if next_batch is not None else None
         if rt.ready is not None:
             torch.cuda.current_stream().wait_event(rt.ready)
         loss = self.run(rt, opt)
+        if begun is not None:
+            self._pending = self._finish_ahead(begun)
         # side-stream memory of this route may be reused only by a route whose kernels wait for this run(): the next
         # route to be enqueued does (its event is recorded after this point), the one enqueued above does not -- so
         # the route stays referenced until the step after this one
