@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void hconv_pool_fwd_kernel(const float* __rest
 // One workgroup owns 16 sequences and the PAIR of heights (hA, hB = L + 1 - hA): every pair costs the same 2 hA hB row
 // products per column, and its L + 1 positions split evenly over the four waves (hA's extra positions go to the first
 // waves, hB's to the last: 94 % balance over all pairs at L = 50).  The wave keeps the accumulators of its positions
-// (<= 16 of hA, <= 8 of hB) in registers across the whole K loop: for each 16-column chunk cb the workgroup stages
+// (<= 16 of hA, <= 8 of hB, <= 18 together) in registers across the whole K loop: for each 16-column chunk cb the workgroup stages
 // e[16 sequences, L rows, 16 columns] (L KB) into LDS with coalesced loads, then each wave runs over the filter rows r:
 // one 16-byte B operand per lane from global memory (the four waves read the same rows: vector-L1 hits, requested four
 // rows ahead) and one ds_read_b128 per (r, position) for A, four MFMAs each.  Measured on the way here (C5 shape): the
@@ -124,50 +124,61 @@ typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
                    // no barriers, 4 no LDS reads, 5 staging reads 16 hot sequences, 6 one workgroup per CU, 7 staging
                    // without the LDS stores, 8 without the global loads
 #endif
-constexpr int HC_NA = 16;   // positions per wave of the pair's lower height (T <= 64)
-constexpr int HC_NB = 8;    // ... of its upper height (T <= 32)
-// one accumulator file for both heights: the lower height's positions fill it from the front, the upper height's from
-// the back; a wave holds at most (T_A + 3) / 4 + (T_B + 3) / 4 <= (L + 1) / 4 + 2 <= 18 positions
-constexpr int HC_NACC = 18;
+// Accumulators of a wave: its positions of one height are taken in groups of four ("quads", MFMAs of a quad interleaved
+// so that no accumulator is touched twice in a row) plus a tail of up to three.  One file of four quads serves both
+// heights -- the lower height's quads fill it from the front, the upper height's from the back: a wave holds at most
+// (T_A + 3) / 4 + (T_B + 3) / 4 <= (L + 1) / 4 + 2 <= 18 positions, i.e. at most 4 whole quads -- and each height has its
+// own three tail accumulators.  The position COUNTS are run-time values tested by uniform branches; every accumulator
+// index is a compile-time constant.  (The first version of this kernel dispatched on the count with a switch over
+// templates: the compiler then kept two copies of the accumulator file, ~60 v_mov_b64 around every case, 219 VGPRs.)
+constexpr int HC_NQ = 4;
 
-// N positions t_start .. t_start + N - 1 of height hh, one column chunk: acc[..] += sum_r <slab row t + r, filter row r>.
+// positions t_start .. t_start + 4 nq + nt - 1 of height hh, one column chunk: acc += sum_r <slab row t + r, filter row r>.
 // slab: the staged chunk + 4 * lane (row s at slab + 256 s); wr: the lane's filter row 0 of this chunk (row r at wr + r d).
-// Position tt accumulates in acc[tt] (DIR = 1) or acc[HC_NACC - 1 - tt] (DIR = -1).  The positions go in NQ groups of
-// <= 4, as even as possible: a lone position would make its four MFMAs a dependent chain.  (Requesting a group's A
-// operands one group ahead from two register buffers, with the scheduler fenced, cost 66 registers and gained 1 %.)
-template <int N, int DIR>
-__device__ __forceinline__ void hc_rows(hc_f32x4 (&acc)[HC_NACC], const float* __restrict__ slab,
-                                        const float* __restrict__ wr, int d, int hh, int t_start) {
-    constexpr int NQ = (N + 3) / 4, QB = N / NQ, QX = N % NQ;   // group x: QB + (x < QX) positions from x QB + min(x, QX)
+// Quad x accumulates in accq[x] (DIR = 1) or accq[HC_NQ - 1 - x] (DIR = -1).
+template <int DIR>
+__device__ __forceinline__ void hc_rows(hc_f32x4 (&accq)[HC_NQ][4], hc_f32x4 (&tail)[3], const float* __restrict__ slab,
+                                        const float* __restrict__ wr, int d, int hh, int t_start, int nq, int nt) {
     constexpr int RD = 4;                   // filter rows in flight (8 for waves with few positions: no faster)
     hc_f32x4 b[RD];
 #pragma unroll
     for (int u = 0; u < RD; ++u) b[u] = HC_LD4(wr + (int64_t)(u < hh ? u : hh - 1) * d);
     const float* ap = slab + t_start * 256;
+    const float* at = ap + 4 * nq * 256;    // the tail's first position
     for (int r0 = 0; r0 < hh; r0 += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
             if (r0 + u < hh) {
                 const float* ar = ap + (r0 + u) * 256;
 #pragma unroll
-                for (int x = 0; x < NQ; ++x) {
-                    const int sz = QB + (x < QX ? 1 : 0), st = x * QB + (x < QX ? x : QX);
-                    hc_f32x4 a[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#if HC_ABL == 4
-                        if (k < sz) a[k] = b[(u + k) % RD];
-#else
-                        if (k < sz) a[k] = HC_LD4(ar + (st + k) * 256);
-#endif
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                for (int x = 0; x < HC_NQ; ++x)
+                    if (x < nq) {
+                        hc_f32x4 a[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (k < sz) {
-                                hc_f32x4& c = acc[DIR > 0 ? st + k : HC_NACC - 1 - st - k];
+#if HC_ABL == 4
+                            a[k] = b[(u + k) % RD];
+#else
+                            a[k] = HC_LD4(ar + (4 * x + k) * 256);
+#endif
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                hc_f32x4& c = accq[DIR > 0 ? x : HC_NQ - 1 - x][k];
                                 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][j], b[u][j], c, 0, 0, 0);
                             }
+                    }
+                if (nt > 0) {
+                    const float* atr = at + (r0 + u) * 256;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (k < nt) {
+                            const hc_f32x4 a = HC_LD4(atr + k * 256);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                tail[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[u][j], tail[k], 0, 0, 0);
+                        }
                 }
             }
             const int rn = r0 + u + RD;     // rows past the end: clamped, unused
@@ -178,39 +189,33 @@ __device__ __forceinline__ void hc_rows(hc_f32x4 (&acc)[HC_NACC], const float* _
     }
 }
 
+// the wave's best position of one height -> LDS (float best, int position) per (lane, v); positions in ascending order
 template <int DIR>
-__device__ __forceinline__ void hc_rows_n(int n, hc_f32x4 (&acc)[HC_NACC], const float* slab, const float* wr, int d,
-                                          int hh, int t_start) {
-    switch (n) {
-#define HC_CASE(N_) case N_: hc_rows<N_, DIR>(acc, slab, wr, d, hh, t_start); break;
-        HC_CASE(1) HC_CASE(2) HC_CASE(3) HC_CASE(4) HC_CASE(5) HC_CASE(6) HC_CASE(7) HC_CASE(8)
-        default:
-            if constexpr (DIR > 0) {        // the lower height of a pair: up to 16 positions per wave
-                switch (n) {
-                    HC_CASE(9) HC_CASE(10) HC_CASE(11) HC_CASE(12) HC_CASE(13) HC_CASE(14) HC_CASE(15) HC_CASE(16)
-                    default: break;
-                }
-            }
-            break;
-#undef HC_CASE
-    }
-}
-
-// the wave's best position of one height -> LDS (float best, int position) per (lane, v)
-template <int DIR, int NMAX>
-__device__ __forceinline__ void hc_wave_best(const hc_f32x4 (&acc)[HC_NACC], int n, int t_start, float bv, float* bests,
-                                             int* bts, int wave, int lane) {
+__device__ __forceinline__ void hc_wave_best(const hc_f32x4 (&accq)[HC_NQ][4], const hc_f32x4 (&tail)[3], int nq, int nt,
+                                             int t_start, float bv, float* bests, int* bts, int wave, int lane) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         float best = -INFINITY;
         int bt = 0;
 #pragma unroll
-        for (int tt = 0; tt < NMAX; ++tt)
-            if (tt < n) {
-                const float val = acc[DIR > 0 ? tt : HC_NACC - 1 - tt][v] + bv;
+        for (int x = 0; x < HC_NQ; ++x)
+            if (x < nq) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float val = accq[DIR > 0 ? x : HC_NQ - 1 - x][k][v] + bv;
+                    if (val > best) {
+                        best = val;
+                        bt = t_start + 4 * x + k;
+                    }
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < nt) {
+                const float val = tail[k][v] + bv;
                 if (val > best) {
                     best = val;
-                    bt = t_start + tt;
+                    bt = t_start + 4 * nq + k;
                 }
             }
         bests[(wave * 4 + v) * 64 + lane] = best;
@@ -218,7 +223,10 @@ __device__ __forceinline__ void hc_wave_best(const hc_f32x4 (&acc)[HC_NACC], int
     }
 }
 
-__global__ __launch_bounds__(256, 2) void hconv_direct_fwd_kernel(const float* __restrict__ e, const float* __restrict__ W,
+#ifndef HC_LB
+#define HC_LB 3   // workgroups per CU the register budget is cut for (LDS: L KB each)
+#endif
+__global__ __launch_bounds__(256, HC_LB) void hconv_direct_fwd_kernel(const float* __restrict__ e, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, int64_t B, int L, int C,
                                                                   int d, int nsg, float* __restrict__ out,
                                                                   int32_t* __restrict__ arg) {
@@ -240,14 +248,18 @@ __global__ __launch_bounds__(256, 2) void hconv_direct_fwd_kernel(const float* _
     const float* eg = e + (HC_ABL == 5 ? (int64_t)i : seq) * L * d + 4 * q;                                   // + s d + 16 cb
     const float* wA = W + (hc_off(C, hA) + (int64_t)filt * hA) * d + 4 * q;      // + r d + 16 cb
     const float* wB = W + (hc_off(C, hB) + (int64_t)filt * hB) * d + 4 * q;
-    hc_f32x4 acc[HC_NACC];
+    hc_f32x4 accq[HC_NQ][4], tailA[3], tailB[3];
 #pragma unroll
-    for (int t = 0; t < HC_NACC; ++t) acc[t] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int x = 0; x < HC_NQ; ++x)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) accq[x][k] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tailA[k] = tailB[k] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const float* slab = lds + 4 * lane;
     const int ncb = d / 16;
     for (int cb = 0; cb < ncb; ++cb) {
 #ifndef HC_SB
-#define HC_SB 16
+#define HC_SB 13
 #endif
         // wave w stages rows w, w + 4, ...: the loads of a batch of HC_SB rows in flight before the barrier / the stores
         for (int sb = 0; sb < ((HC_ABL == 1 || HC_ABL == 3) ? 0 : L); sb += 4 * HC_SB) {
@@ -277,14 +289,14 @@ __global__ __launch_bounds__(256, 2) void hconv_direct_fwd_kernel(const float* _
 #if HC_ABL != 3
         __syncthreads();
 #endif
-        hc_rows_n<1>(nA, acc, slab, wA + cb * 16, d, hA, tA);
-        hc_rows_n<-1>(nB, acc, slab, wB + cb * 16, d, hB, tB);
+        hc_rows<1>(accq, tailA, slab, wA + cb * 16, d, hA, tA, nA >> 2, nA & 3);
+        if (nB) hc_rows<-1>(accq, tailB, slab, wB + cb * 16, d, hB, tB, nB >> 2, nB & 3);
     }
     __syncthreads();
     float* bests = lds;                                         // [height A / B][wave][v][lane]
     int* bts = reinterpret_cast<int*>(lds + 2 * 1024);
-    hc_wave_best<1, HC_NA>(acc, nA, tA, bias[(hA - 1) * C + filt], bests, bts, wave, lane);
-    hc_wave_best<-1, HC_NB>(acc, nB, tB, bias[(hB - 1) * C + filt], bests + 1024, bts + 1024, wave, lane);
+    hc_wave_best<1>(accq, tailA, nA >> 2, nA & 3, tA, bias[(hA - 1) * C + filt], bests, bts, wave, lane);
+    hc_wave_best<-1>(accq, tailB, nB >> 2, nB & 3, tB, bias[(hB - 1) * C + filt], bests + 1024, bts + 1024, wave, lane);
     __syncthreads();
     // thread (wave, lane) finishes v = wave of both heights: waves in ascending position order, the first maximum wins
     const int64_t sq = s0 + 4 * q + wave;
