@@ -322,6 +322,170 @@ __global__ __launch_bounds__(256, HC_LB) void hconv_direct_fwd_kernel(const floa
     }
 }
 
+// ---- the same kernel over 32-column chunks, two height pairs per workgroup (d % 32 == 0) -----------------------------
+// What the 16-column version above still pays for is its staging: every wave-load there covers 16 sequences x 64 bytes,
+// half cache lines.  Here a chunk is 32 columns = one full 128-byte line per (sequence, row): a staging wave-load covers
+// 8 sequences x 128 bytes, the chunk (2 L KB) is staged once for TWO height pairs of neighbouring cost (waves 0-3 and
+// 4-7 of a 512-thread workgroup; one workgroup per CU), and there are half as many barriers per sequence group.
+// LDS row s: [half 0 / 1][q][sequence slot][4 floats], slot = sequence ^ (2 q + half) -- lane (i, q) reads columns 8 q .. 8 q + 3 (half 0) and 8 q + 4 .. 8 q + 7
+// (half 1) as two conflict-free ds_read_b128; MFMA j < 8 contracts column 8 q + j over q.
+template <int DIR>
+__device__ __forceinline__ void hc2_rows(hc_f32x4 (&accq)[HC_NQ][4], hc_f32x4 (&tail)[3], const float* __restrict__ slab,
+                                         const float* __restrict__ slab1, const float* __restrict__ wr, int d, int hh, int t_start, int nq, int nt) {
+    constexpr int RD = 4;
+    hc_f32x4 b[RD][2];
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+        const float* p = wr + (int64_t)(u < hh ? u : hh - 1) * d;
+        b[u][0] = HC_LD4(p);
+        b[u][1] = HC_LD4(p + 4);
+    }
+    const float* ap = slab + t_start * 512;
+    const float* ap1 = slab1 + t_start * 512;
+    const float* at = ap + 4 * nq * 512;
+    const float* at1 = ap1 + 4 * nq * 512;
+    for (int r0 = 0; r0 < hh; r0 += RD) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            if (r0 + u < hh) {
+                const float* ar = ap + (r0 + u) * 512;
+                const float* ar1 = ap1 + (r0 + u) * 512;
+#pragma unroll
+                for (int x = 0; x < HC_NQ; ++x)
+                    if (x < nq) {
+                        hc_f32x4 a[4][2];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            a[k][0] = HC_LD4(ar + (4 * x + k) * 512);
+                            a[k][1] = HC_LD4(ar1 + (4 * x + k) * 512);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                hc_f32x4& c = accq[DIR > 0 ? x : HC_NQ - 1 - x][k];
+                                c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][j >> 2][j & 3], b[u][j >> 2][j & 3], c, 0, 0, 0);
+                            }
+                    }
+                if (nt > 0) {
+                    const float* atr = at + (r0 + u) * 512;
+                    const float* atr1 = at1 + (r0 + u) * 512;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (k < nt) {
+                            const hc_f32x4 a0 = HC_LD4(atr + k * 512), a1 = HC_LD4(atr1 + k * 512);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                tail[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[u][0][j], tail[k], 0, 0, 0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                tail[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b[u][1][j], tail[k], 0, 0, 0);
+                        }
+                }
+            }
+            const int rn = r0 + u + RD;     // rows past the end: clamped, unused
+            const float* p = wr + (int64_t)(rn < hh ? rn : hh - 1) * d;
+            b[u][0] = HC_LD4(p);
+            b[u][1] = HC_LD4(p + 4);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void hconv_direct2_fwd_kernel(const float* __restrict__ e, const float* __restrict__ W,
+                                                                   const float* __restrict__ bias, int64_t B, int L, int C,
+                                                                   int d, int nsg, float* __restrict__ out,
+                                                                   int32_t* __restrict__ arg) {
+    extern __shared__ float lds[];          // [L rows][2 halves][4 q][16 sequences][4]; the epilogue's 32 KB reuse it
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, side = wave8 >> 2;
+    const int i = lane & 15, q = lane >> 4;
+    const int npairs = (L + 1) / 2;
+    // duo dd = the pairs of cost rank 2 dd and 2 dd + 1 (neighbours: nearly the same cost); costliest duos first
+    const int dd = (int)(blockIdx.x / nsg);
+    const int pr = npairs - 1 - (2 * dd + side);
+    const bool live = pr >= 0;              // an odd number of pairs: the last duo's second half only keeps the barriers
+    const int hA = live ? pr + 1 : 1, hB = live ? L - pr : 1;
+    const int64_t s0 = (int64_t)(blockIdx.x % nsg) * 16;
+    const int TA = live ? L + 1 - hA : 0, TB = (live && hB != hA) ? L + 1 - hB : 0;
+    const int nA = TA / 4 + (wave < TA % 4 ? 1 : 0);
+    const int tA = wave * (TA / 4) + (wave < TA % 4 ? wave : TA % 4);
+    const int xB = 4 - TB % 4;
+    const int nB = TB / 4 + ((TB % 4) && wave >= xB ? 1 : 0);
+    const int tB = wave * (TB / 4) + ((TB % 4) && wave > xB ? wave - xB : 0);
+    const int filt = i < C ? i : C - 1;
+    const float* wA = W + (hc_off(C, hA) + (int64_t)filt * hA) * d + 8 * q;      // + r d + 32 cb
+    const float* wB = W + (hc_off(C, hB) + (int64_t)filt * hB) * d + 8 * q;
+    // staging: lane = (sequence % 8, 16-byte column group g = 2 q' + half); a wave-load = 8 sequences x one 128-byte line
+    const int sg = lane >> 3, cg = lane & 7;
+    const int64_t seq0 = (s0 + sg < B) ? s0 + sg : B - 1, seq1 = (s0 + 8 + sg < B) ? s0 + 8 + sg : B - 1;
+    const float* eg0 = e + seq0 * L * d + 4 * cg;
+    const float* eg1 = e + seq1 * L * d + 4 * cg;
+    // float offset inside an LDS row; the sequence slot is XORed with the column group so that the eight lanes one LDS
+    // cycle serves (one sequence, eight column groups) hit eight different bank quads -- readers undo it (slab / slab1)
+    const int so0 = (cg & 1) * 256 + (cg >> 1) * 64 + (sg ^ cg) * 4, so1 = so0 + 32;
+    hc_f32x4 accq[HC_NQ][4], tailA[3], tailB[3];
+#pragma unroll
+    for (int x = 0; x < HC_NQ; ++x)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) accq[x][k] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tailA[k] = tailB[k] = (hc_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const float* slab = lds + q * 64 + (i ^ (2 * q)) * 4;
+    const float* slab1 = lds + 256 + q * 64 + (i ^ (2 * q + 1)) * 4;
+    const int ncb = d / 32;
+    for (int cb = 0; cb < ncb; ++cb) {
+        // wave w stages rows w, w + 8, ...: both halves of the 16 sequences, all loads in flight before the barrier
+        constexpr int SB = (HC_MAX_L + 7) / 8;
+        hc_f32x4 v[SB][2];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+            const int s = 8 * k + wave8;
+            const int64_t o = (int64_t)(s < L ? s : L - 1) * d + cb * 32;
+            v[k][0] = HC_LD4(eg0 + o);
+            v[k][1] = HC_LD4(eg1 + o);
+        }
+        __syncthreads();                    // the previous chunk's readers are done
+#pragma unroll
+        for (int k = 0; k < SB; ++k) {
+            const int s = 8 * k + wave8;
+            if (s < L) {
+                *reinterpret_cast<hc_f32x4*>(lds + s * 512 + so0) = v[k][0];
+                *reinterpret_cast<hc_f32x4*>(lds + s * 512 + so1) = v[k][1];
+            }
+        }
+        __syncthreads();
+        if (nA) hc2_rows<1>(accq, tailA, slab, slab1, wA + cb * 32, d, hA, tA, nA >> 2, nA & 3);
+        if (nB) hc2_rows<-1>(accq, tailB, slab, slab1, wB + cb * 32, d, hB, tB, nB >> 2, nB & 3);
+    }
+    __syncthreads();
+    float* bests = lds + side * 4096;                           // [side][height A / B][wave][v][lane]
+    int* bts = reinterpret_cast<int*>(lds + side * 4096 + 2048);
+    hc_wave_best<1>(accq, tailA, nA >> 2, nA & 3, tA, bias[(hA - 1) * C + filt], bests, bts, wave, lane);
+    hc_wave_best<-1>(accq, tailB, nB >> 2, nB & 3, tB, bias[(hB - 1) * C + filt], bests + 1024, bts + 1024, wave, lane);
+    __syncthreads();
+    const int64_t sq = s0 + 4 * q + wave;
+    if (live && i < C && sq < B) {
+#pragma unroll
+        for (int hx = 0; hx < 2; ++hx) {
+            if (hx == 1 && TB == 0) break;
+            const int hh = hx ? hB : hA;
+            float best = -INFINITY;
+            int bt = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float v = bests[hx * 1024 + (w * 4 + wave) * 64 + lane];
+                if (v > best) {
+                    best = v;
+                    bt = bts[hx * 1024 + (w * 4 + wave) * 64 + lane];
+                }
+            }
+            const int64_t o = sq * ((int64_t)C * L) + (hh - 1) * C + i;
+            out[o] = best > 0.0f ? best : 0.0f;
+            arg[o] = best > 0.0f ? bt : -1;
+        }
+    }
+}
+
 // d e: one workgroup per sequence accumulates its [L, d] tile in LDS; columns V (tid % LPR) .. +V-1 of row p belong to
 // one thread (p % (256 / LPR) = tid / LPR), contributions added in ascending (h, c, r)
 template <int V, int LPR>
@@ -566,6 +730,18 @@ extern "C" int32_t dr_caser_hconv_direct_f32(const float* e, const float* W, con
                "dr_caser_hconv_direct_f32: NULL / misaligned pointer");
     const int64_t nsg = (B + 15) / 16;
     const int npairs = (L + 1) / 2;
+    if (d % 32 == 0 && getenv("DR_HCONV_16COL") == nullptr) {    // 32-column chunks, two height pairs per workgroup
+        const int nduo = (npairs + 1) / 2;
+        DR_REQUIRE(nsg * nduo < (1ll << 31) - 1, "dr_caser_hconv_direct_f32: grid too large");
+        size_t lds2 = (size_t)L * 2048;
+        if (lds2 < 32 * 1024) lds2 = 32 * 1024;
+        DR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hconv_direct2_fwd_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        DR_LAUNCH_NAMED("hconv_direct2_fwd_kernel", hconv_direct2_fwd_kernel, dim3((unsigned)(nsg * nduo)), dim3(512), lds2,
+                        (hipStream_t)stream, e, W, bias, B, (int)L, (int)C, (int)d, (int)nsg, out, arg);
+        DR_CHECK_LAUNCH("hconv_direct2_fwd_kernel");
+        return DR_OK;
+    }
     DR_REQUIRE(nsg * npairs < (1ll << 31) - 1, "dr_caser_hconv_direct_f32: grid too large");
     size_t lds = (size_t)L * 1024;          // the staged chunk; the epilogue needs 16 KB
     if (lds < 16 * 1024) lds = 16 * 1024;
