@@ -973,7 +973,7 @@ def test_attn_pool_rejects_bad_shapes(dev):
 
 # ------------------------------------------------------------------ Caser horizontal convolutions
 @pytest.mark.parametrize("B,L,d,C", [(5, 5, 16, 4), (300, 7, 30, 3), (600, 50, 128, 16), (3, 64, 256, 2), (2, 1, 8, 1),
-                                     (77, 19, 32, 16), (130, 9, 48, 5)])
+                                     (77, 19, 32, 16), (130, 9, 48, 5), (20, 5, 64, 16), (33, 1, 32, 7), (18, 2, 96, 3)])
 def test_caser_hconv_forward_backward(dev, B, L, d, C):
     """dr_caser_hconv_pool_f32 / _backward_input_f32 / _backward_filter_f32 (Caser.py:132-154): pooled output and winning
     positions against the oracle's literal convolution, gradients against float64 autograd through the library form
