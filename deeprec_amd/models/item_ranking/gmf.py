@@ -139,8 +139,20 @@ class GMF(object):
         i = to_dev(np.asarray(item_id).reshape(-1), torch.int32, self.device)
         return K.pointwise_forward(self.P, self.Q, u, i, K.LOSS_BCE).cpu().numpy()
 
+    def eval_score_chunks(self, users, chunk=None):
+        """Yields (c0, c1, sigmoid scores [c1 - c0, num_item]) for consecutive chunks of `users` (MFMA GEMM); the
+        evaluator selects per chunk, so the [users, items] matrix never exists.  The reference ranks the SIGMOID
+        (gmf.py:70, RankingMetrics.py:82-101), which saturates in fp32 and then ties: the scores, not the dots, are
+        what the selection sees."""
+        users = list(users)
+        if chunk is None:
+            chunk = max(1, min(len(users), (1 << 26) // max(1, self.num_item)))
+        for c0 in range(0, len(users), chunk):
+            u = to_dev(np.asarray(users[c0:c0 + chunk]), torch.int32, self.device)
+            yield c0, c0 + len(u), K.score_matrix(K.gather(self.P, u), self.Q, sigmoid=True)
+
     def eval_scores(self, users):
-        """Full-catalog sigmoid scores [len(users), num_item] through the MFMA GEMM (evaluator fast path)."""
+        """Full-catalog sigmoid scores [len(users), num_item] in one tensor (tests, small catalogs)."""
         u = to_dev(np.asarray(list(users)), torch.int32, self.device)
         return K.score_matrix(K.gather(self.P, u), self.Q, sigmoid=True)
 
