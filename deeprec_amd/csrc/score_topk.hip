@@ -594,8 +594,13 @@ __device__ __forceinline__ void load_areg(float (&areg)[KS], const ScoreArgs& a,
 // one block's MFMA stream covers the other's staging and selection stalls.  fp32 MFMA shares the SIMD's vector
 // pipe with ordinary VALU work (measured: a barrier-locked two-group ping-pong form ran no faster), so what
 // counts is the number of non-MFMA instructions per tile.
+#ifndef DR_SCORE_LB128
+#define DR_SCORE_LB128 1   // k in (128, 256]: the 128-register user panel leaves no room for two workgroups per CU without
+                           // spilling 76-115 registers to memory; one per CU spills to AGPRs only: C5 evaluation 59.2 -> 47.0 ms
+#endif
+#define SCORE_LB(KS_) ((KS_) >= 128 ? DR_SCORE_LB128 : 2)
 template <bool MATRIX, int KS, bool VEC, bool BAND = false>
-__global__ __launch_bounds__(256, 2) void score_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(256, SCORE_LB(KS)) void score_kernel(ScoreArgs a) {
     using G = Geo<KS, VEC>;
     extern __shared__ __align__(16) float smem[];
     float* sI = smem;  // [TI][LDP], k-permuted (see LDP)
