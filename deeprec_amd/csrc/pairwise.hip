@@ -297,19 +297,33 @@ __global__ __launch_bounds__(256) void bpr_forward_update_1col_kernel(FusedTable
         }
         const bool vu = live && iu >= 0 && iu < nu, vi = live && ii >= 0 && ii < ni, vj = live && ij >= 0 && ij < ni;
         const bool ok = vu && vi && vj;
-        const int64_t ou = iu * k + lane * V, oi = ii * k + lane * V, oj = ij * k + lane * V;
+        // Row loads are UNCONDITIONAL (an id out of range reads row 0 and is zeroed by a select afterwards) and the slot
+        // registers carry no initial value: written as `x = 0; if (valid) load(x)` every load was followed by
+        // s_waitcnt vmcnt(0) -- the zero written on the other path may not overtake a load in flight into the same
+        // register -- so the three row fetches of a sample were three random-HBM round trips in a row, not one.
+        const int64_t ou = (vu ? iu : 0) * k + lane * V, oi = (vi ? ii : 0) * k + lane * V, oj = (vj ? ij : 0) * k + lane * V;
         float pu[V], qi[V], qj[V], mu[V], vu2[V], mi[V], vi2[V], mj[V], vj2[V];
+        vload<V>(pu, t.p.table + ou);
+        vload<V>(qi, t.q.table + oi);
+        vload<V>(qj, t.q.table + oj);
+        if (su) {   // solo rows are valid rows; slots beyond the optimizer's are never read
+            if (nsl >= 1) vload<V>(mu, t.p.slot0 + ou);
+            if (nsl >= 2) vload<V>(vu2, t.p.slot1 + ou);
+        }
+        if (si) {
+            if (nsl >= 1) vload<V>(mi, t.q.slot0 + oi);
+            if (nsl >= 2) vload<V>(vi2, t.q.slot1 + oi);
+        }
+        if (sj) {
+            if (nsl >= 1) vload<V>(mj, t.q.slot0 + oj);
+            if (nsl >= 2) vload<V>(vj2, t.q.slot1 + oj);
+        }
 #pragma unroll
-        for (int x = 0; x < V; ++x) pu[x] = qi[x] = qj[x] = mu[x] = vu2[x] = mi[x] = vi2[x] = mj[x] = vj2[x] = 0.0f;
-        if (vu) vload<V>(pu, t.p.table + ou);
-        if (vi) vload<V>(qi, t.q.table + oi);
-        if (vj) vload<V>(qj, t.q.table + oj);
-        if (su && nsl >= 1) vload<V>(mu, t.p.slot0 + ou);
-        if (su && nsl >= 2) vload<V>(vu2, t.p.slot1 + ou);
-        if (si && nsl >= 1) vload<V>(mi, t.q.slot0 + oi);
-        if (si && nsl >= 2) vload<V>(vi2, t.q.slot1 + oi);
-        if (sj && nsl >= 1) vload<V>(mj, t.q.slot0 + oj);
-        if (sj && nsl >= 2) vload<V>(vj2, t.q.slot1 + oj);
+        for (int x = 0; x < V; ++x) {
+            pu[x] = vu ? pu[x] : 0.0f;
+            qi[x] = vi ? qi[x] : 0.0f;
+            qj[x] = vj ? qj[x] : 0.0f;
+        }
         float xui = 0.0f, xuj = 0.0f;
         if (ok) {
 #pragma unroll
