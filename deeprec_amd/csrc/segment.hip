@@ -442,16 +442,21 @@ __device__ __forceinline__ void block_sum(const SegArgs& a, int y0, int y1, int 
         const int n = y1 - y;  // >= 1; entries q >= n do not exist
         float v[UNR][V];
         float cf[UNR];
-        int si[UNR];
+        int si[UNR], sp[UNR];
+        // Index loads are unconditional (entries past the end re-read the last one and are dropped by a select) and go
+        // level by level: written per entry as `if (q < n) { si = msrc[..]; cf = coef[spos[..]]; }` the compiler waited
+        // (vmcnt(0)) inside every entry for its position before it could request the coefficient -- 16 dependent round
+        // trips per pass where three levels suffice: {msrc, spos} -> coef -> rows.
 #pragma unroll
         for (int q = 0; q < UNR; ++q) {
-            si[q] = -1;
-            cf[q] = 1.0f;
-            if (q < n) {
-                si[q] = a.msrc[y + q];
-                if (a.coef) cf[q] = a.coef[a.spos[y + q] - a.pos_lo];
-            }
+            const int yy = (q < n) ? y + q : y1 - 1;
+            si[q] = a.msrc[yy];
+            sp[q] = a.coef ? a.spos[yy] : 0;
         }
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) cf[q] = a.coef ? a.coef[sp[q] - a.pos_lo] : 1.0f;
+#pragma unroll
+        for (int q = 0; q < UNR; ++q) si[q] = (q < n) ? si[q] : -1;
 #pragma unroll
         for (int q = 0; q < UNR; ++q)
             if (si[q] >= 0) vload<V>(v[q], seg_src_row(a, si[q]) + c * V);
