@@ -745,7 +745,14 @@ __global__ __launch_bounds__(256) void bpr_tail_combine_kernel(TailArgs t) {
         if ((int64_t)r >= a.rows) continue;
         const int nch = (a.seg_start[s + 1] - a.seg_start[s] + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK;
         const float* part = a.partials + (int64_t)a.long_cb[l] * k;
+        const int ns = KIND == DR_OPT_ADAM ? 2 : kind_slots(a.kind);
         for (int c = lane; c < cpr; c += LPR) {
+            // the destination row's (w, m, v) are requested before the partial rows: one round trip less per row
+            const int64_t off = (int64_t)r * k + c * V;
+            float wv[V], s0[V], s1[V];
+            vload<V>(wv, a.table + off);
+            if (ns >= 1) vload<V>(s0, a.slot0 + off);
+            if (ns >= 2) vload<V>(s1, a.slot1 + off);
             float tot[V];
 #pragma unroll
             for (int x = 0; x < V; ++x) tot[x] = 0.0f;
@@ -772,13 +779,20 @@ __global__ __launch_bounds__(256) void bpr_tail_combine_kernel(TailArgs t) {
                     for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[q][x];
                 }
             }
-            for (; ch < nch; ++ch) {
-                float v[V];
-                vload<V>(v, part + (int64_t)ch * k + c * V);
+            if (ch < nch) {   // the last < 8 partial rows: one predicated batch, not a load-add chain per row
+                float v[8][V];
 #pragma unroll
-                for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[x];
+                for (int q = 0; q < 8; ++q)
+                    vload<V>(v[q], part + (int64_t)(ch + q < nch ? ch + q : nch - 1) * k + c * V);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (ch + q < nch) {
+#pragma unroll
+                        for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[q][x];
+                    }
+                }
             }
-            apply_row<V, KIND>(a, r, c, tot);
+            apply_row_loaded<V, KIND>(a, r, c, tot, wv, s0, s1);
         }
     }
 }
