@@ -228,11 +228,37 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
     // memory side of this multi-XCD part (~8 ns each: 20 k per-row atomics made this kernel 22 us).  So: ONE atomic per
     // workgroup and pass for the (many) rows with 2 .. LONG_SEG contributions, one per wavefront for the (few) long rows.
     __shared__ int wcnt[4], wbase[4];
+    __shared__ int blk_base;
     const int nseg = hdr[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t s0 = (int64_t)blockIdx.x * 256; s0 < nseg; s0 += stride) {   // block-uniform trip count
-        const int64_t s = s0 + threadIdx.x;
+    // a workgroup owns a CONTIGUOUS range of 256-segment passes: with many passes per workgroup (4 M ids: 13 k passes)
+    // it first counts its rows with 2 .. LONG_SEG contributions and reserves their descriptors with ONE atomic (one per
+    // pass made this kernel 173 us of the 400 us plan at 4 M ids), then writes them in a second walk
+    const int64_t passes = ((int64_t)nseg + 255) / 256;
+    const int64_t ppb = (passes + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb, p1 = (p0 + ppb < passes) ? p0 + ppb : passes;
+    int run = 0;                        // next free descriptor of this workgroup (block-uniform)
+    if (ppb > 1) {
+        int mine = 0;
+        for (int64_t ps = p0; ps < p1; ++ps) {
+            const int64_t s = ps * 256 + threadIdx.x;
+            const int len = s < nseg ? seg_start[s + 1] - seg_start[s] : 0;
+            mine += (len >= 2 && len <= LONG_SEG) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+        if (lane == 0) wcnt[wave] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            blk_base = t ? atomicAdd(&hdr[4], t) : 0;
+        }
+        __syncthreads();
+        run = blk_base;
+        __syncthreads();
+    }
+    for (int64_t ps = p0; ps < p1; ++ps) {   // block-uniform trip count
+        const int64_t s = ps * 256 + threadIdx.x;
         const int first = s < nseg ? seg_start[s] : 0;
         const int len = s < nseg ? seg_start[s + 1] - first : 0;
         // long rows: count and block total of this wavefront, one atomic each
@@ -269,7 +295,7 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
         __syncthreads();
         if (threadIdx.x == 0) {
             const int t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-            int base = t ? atomicAdd(&hdr[4], t) : 0;
+            int base = (ppb > 1) ? run : (t ? atomicAdd(&hdr[4], t) : 0);
             for (int w = 0; w < 4; ++w) {
                 wbase[w] = base;
                 base += wcnt[w];
@@ -278,6 +304,7 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
         __syncthreads();
         // one 16-byte descriptor per row: the tail kernel then needs ONE load where it walked multi -> uniq / seg_start
         if (is_multi) multi[wbase[wave] + __popcll(m & ((1ull << lane) - 1ull))] = make_int4((int)s, uniq[s], first, len);
+        run += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
         __syncthreads();
     }
 }
