@@ -639,6 +639,18 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
 #pragma unroll
             for (int x = 0; x < V; ++x) tot[x] = 0.0f;
             int ch = 0;
+            // same sequence of additions; 32 (then 8) partial rows requested per round trip, the last < 8 as one
+            // predicated batch instead of a load-add chain per row
+            for (; ch + 32 <= nch; ch += 32) {
+                float v[32][V];
+#pragma unroll
+                for (int q = 0; q < 32; ++q) vload<V>(v[q], part + (int64_t)(ch + q) * a.k + c * V);
+#pragma unroll
+                for (int q = 0; q < 32; ++q) {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[q][x];
+                }
+            }
             for (; ch + 8 <= nch; ch += 8) {
                 float v[8][V];
 #pragma unroll
@@ -649,11 +661,18 @@ __global__ __launch_bounds__(256) void seg_long_combine_kernel(SegArgs a) {
                     for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[q][x];
                 }
             }
-            for (; ch < nch; ++ch) {
-                float v[V];
-                vload<V>(v, part + (int64_t)ch * a.k + c * V);
+            if (ch < nch) {
+                float v[8][V];
 #pragma unroll
-                for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[x];
+                for (int q = 0; q < 8; ++q)
+                    vload<V>(v[q], part + (int64_t)(ch + q < nch ? ch + q : nch - 1) * a.k + c * V);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (ch + q < nch) {
+#pragma unroll
+                        for (int x = 0; x < V; ++x) tot[x] = tot[x] + v[q][x];
+                    }
+                }
             }
             apply_row<V>(a, r, c, tot);
         }
