@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""cProfile of the host side of the pipelined row-sharded step on one GPU through a size-1 RCCL group (dev tool)."""
-import cProfile, os, pstats, sys
+"""cProfile of the host side of ShardedBpr.step at world 1 through RCCL (dev tool)."""
+import cProfile, pstats, os, sys, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
@@ -13,7 +13,7 @@ args = bench.parse()
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29513")
+os.environ.setdefault("MASTER_PORT", "29515")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 batches = bench.make_batches(args, 0, dev, 8)
 Pt = sh.ShardedTable(args.users, args.k, 1, 0, dev, 2)
@@ -23,15 +23,18 @@ Qt.init_normal_(K, 2, 0.01)
 opt = K.opt_params(K.OPT_ADAM, lr=0.05, alpha=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, reg=0.1, reg_mode=K.REG_TOUCHED)
 tr = sh.ShardedBpr(K, Pt, Qt)
 tr.prefetch(*batches[0])
-for t in range(10):
-    tr.step(opt, next_batch=batches[(t + 1) % 8])
+for s in range(20):
+    tr.step(opt, batches[(s + 1) % 8])
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for t in range(100):
-    tr.step(opt, next_batch=batches[(t + 1) % 8])
+N = 200
+for s in range(N):
+    tr.step(opt, batches[(s + 1) % 8])
 torch.cuda.synchronize()
 pr.disable()
-st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+out = io.StringIO()
+st = pstats.Stats(pr, stream=out).sort_stats("tottime")
+st.print_stats(28)
+print(out.getvalue())
 dist.destroy_process_group()
