@@ -14,7 +14,26 @@ struct RouteLayout {
     int64_t keys_in, keys_out, vals_in, vals_out, flags, segidx, temp, temp_bytes, total;
 };
 
-static int route_layout(int64_t n, RouteLayout* L) {
+static int route_layout_compute(int64_t n, RouteLayout* L);
+static int route_layout(int64_t n, RouteLayout* L) {   // pure function of n; the rocPRIM size queries are not free
+    static thread_local int64_t memo_n[4] = {-1, -1, -1, -1};
+    static thread_local RouteLayout memo_L[4];
+    static thread_local int next = 0;
+    for (int i = 0; i < 4; ++i)
+        if (memo_n[i] == n) {
+            *L = memo_L[i];
+            return 0;
+        }
+    const int rc = route_layout_compute(n, L);
+    if (rc == 0) {
+        memo_n[next] = n;
+        memo_L[next] = *L;
+        next = (next + 1) % 4;
+    }
+    return rc;
+}
+
+static int route_layout_compute(int64_t n, RouteLayout* L) {
     size_t t_sort = 0, t_scan = 0;
     const int64_t nn = n > 0 ? n : 1;
     hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, int32_t*, int32_t*>(

@@ -48,7 +48,34 @@ using PlanSortConfig = rocprim::radix_sort_config<rocprim::default_config,
                                                   rocprim::default_config, 1024 * 1024>;
 #endif
 
+static int plan_layout_compute(int64_t n, int k_max, PlanLayout* L, char* err);
+// The layout is a pure function of (n, k_max), and every plan / update / size call asks for it: the two rocPRIM
+// temporary-storage queries inside were a measurable part of the host time of a step that issues ~50 short launches
+// (sharded step: 8 queries per step).  The last few answers are kept per host thread.
 static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
+    struct Memo {
+        int64_t n = -1;
+        int k = 0;
+        PlanLayout L;
+    };
+    static thread_local Memo memo[8];
+    static thread_local int next = 0;
+    for (int i = 0; i < 8; ++i)
+        if (memo[i].n == n && memo[i].k == k_max) {
+            *L = memo[i].L;
+            return 0;
+        }
+    const int rc = plan_layout_compute(n, k_max, L, err);
+    if (rc == 0) {
+        memo[next].n = n;
+        memo[next].k = k_max;
+        memo[next].L = *L;
+        next = (next + 1) % 8;
+    }
+    return rc;
+}
+
+static int plan_layout_compute(int64_t n, int k_max, PlanLayout* L, char* err) {
     size_t t_sort = 0, t_scan = 0;
     int64_t nn = n > 0 ? n : 1;
     hipError_t e = rocprim::radix_sort_pairs<PlanSortConfig, uint32_t*, uint32_t*, int32_t*, int32_t*>(
