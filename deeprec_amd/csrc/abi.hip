@@ -52,37 +52,10 @@ __global__ __launch_bounds__(256) void init_normal_kernel(float* __restrict__ w,
         w[i] = stddev * counter_normal(seed, offset + (uint64_t)i);
 }
 
-// One block, fixed order: thread t owns the float4 groups t, t+1024, ... (up to 8 loads in flight, added in index
-// order, lanes of a group in order), then a fixed LDS tree; the tail is added by thread 0 at the end.
+// One block, fixed order (fixed_sum in dr_common.h).
 __global__ __launch_bounds__(1024) void sum_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     __shared__ float red[1024];
-    const bool vec = ((uintptr_t)x % 16) == 0;
-    const int64_t ngrp = vec ? n / 4 : 0;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    float acc = 0.0f;
-    int64_t i = threadIdx.x;
-    for (; i + 7 * 1024 < ngrp; i += 8 * 1024) {
-        float4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = x4[i + q * 1024];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc = (((acc + v[q].x) + v[q].y) + v[q].z) + v[q].w;
-    }
-    for (; i < ngrp; i += 1024) {
-        const float4 v = x4[i];
-        acc = (((acc + v.x) + v.y) + v.z) + v.w;
-    }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        float t = red[0];
-        for (int64_t e = ngrp * 4; e < n; ++e) t += x[e];
-        out[0] = t;
-    }
+    fixed_sum<1024>(x, n, out, red);
 }
 
 __global__ void adam_tick_kernel(float* state, float lr, float beta1, float beta2) {

@@ -148,6 +148,52 @@ __device__ __forceinline__ float subwave_sum(float x) {
     return x;
 }
 
+// ---- the library's fixed-order sum of n floats by ONE block (dr_sum_f32; the fused BPR step's loss) ----
+// 1024 "virtual threads": virtual thread t owns the float4 groups t, t + 1024, ... added in index order (lanes of a
+// group in order), then a fixed tree over the 1024 partial sums in LDS; the < 4 trailing elements are added last.  A
+// block of NT threads (NT divides 1024) runs 1024 / NT virtual threads per thread, so every NT gives the same bits.
+template <int NT>
+__device__ __forceinline__ void fixed_sum(const float* __restrict__ x, int64_t n, float* __restrict__ out, float* red) {
+    constexpr int VT = 1024 / NT;
+    const bool vec = ((uintptr_t)x % 16) == 0;
+    const int64_t ngrp = vec ? n / 4 : 0;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float acc[VT];
+#pragma unroll
+    for (int j = 0; j < VT; ++j) acc[j] = 0.0f;
+    constexpr int DEPTH = VT >= 4 ? 32 / VT : 8;   // loads in flight per thread: VT * DEPTH
+    int64_t i = threadIdx.x;
+    for (; i + (VT - 1) * NT + (DEPTH - 1) * 1024 < ngrp; i += DEPTH * 1024) {
+        float4 v[VT][DEPTH];
+#pragma unroll
+        for (int j = 0; j < VT; ++j)
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) v[j][q] = x4[i + j * NT + q * 1024];
+#pragma unroll
+        for (int j = 0; j < VT; ++j)
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) acc[j] = (((acc[j] + v[j][q].x) + v[j][q].y) + v[j][q].z) + v[j][q].w;
+    }
+#pragma unroll
+    for (int j = 0; j < VT; ++j)
+        for (int64_t g = i + j * NT; g < ngrp; g += 1024) {
+            const float4 v = x4[g];
+            acc[j] = (((acc[j] + v.x) + v.y) + v.z) + v.w;
+        }
+#pragma unroll
+    for (int j = 0; j < VT; ++j) red[threadIdx.x + j * NT] = acc[j];
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        for (int t = threadIdx.x; t < s; t += NT) red[t] += red[t + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float t = red[0];
+        for (int64_t e = ngrp * 4; e < n; ++e) t += x[e];
+        out[0] = t;
+    }
+}
+
 // ---- optimizer row math ([TF-ext] ApplyAdam / ApplyAdagrad / ApplyRMSProp / SGD) ----
 // Separate roundings (the library is built with -ffp-contract=off) so the numpy oracle
 // reproduces the same sequence.

@@ -21,7 +21,7 @@ int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t
 const unsigned char* plan_solo_flags(void* plan, int64_t n, int k);
 int bpr_tail_launch(float* P, float* Ps0, float* Ps1, int64_t nu, float* Q, float* Qs0, float* Qs1, int64_t ni, int k,
                     int64_t B, const float* stash, const float* coefQ, void* plan, int64_t plan_bytes,
-                    const dr_opt_params* opt, hipStream_t st);
+                    const dr_opt_params* opt, hipStream_t st, const float* loss_b, float* loss_out);
 int check_opt(const dr_opt_params* opt, const float* slot0, const float* slot1, const char* who);
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -832,8 +832,9 @@ static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_use
         // are disjoint, Q-side sources are pre-step P rows (in place for non-solo users, the stash copy for solo ones)
         // and P-side sources are stash rows, none of which this launch writes
         rc = bpr_tail_launch(P, Pslot0, Pslot1, num_user, Q, Qslot0, Qslot1, num_item, k, B, stash, coefQ,
-                             base + L.planA, L.plan_bytesA, opt, st);
+                             base + L.planA, L.plan_bytesA, opt, st, loss_b, loss_out);
         if (rc != DR_OK) return rc;
+        return DR_OK;   // the loss was summed by block 0 of the tail's last launch (same order and bits as dr_sum_f32)
     } else if (any) {
         // one combined plan: segments below the split are P rows (contributions = stash rows b), the others Q
         // rows (key - num_user; contributions (+-g_b) * P[u_b]).  Q first: its gradient needs the pre-step P rows.

@@ -723,6 +723,9 @@ struct TailArgs {
     SegArgs p, q;
     const int4* multi;
     int32_t* long_cnt;
+    const float* loss_b;   // per-sample losses of the step and where their sum goes (bpr_tail_combine_kernel's block 0);
+    float* loss_out;       // NULL: no sum
+    int64_t loss_n;
 };
 
 template <int V, int LPR, int KIND>
@@ -801,6 +804,12 @@ __global__ __launch_bounds__(256) void bpr_tail_kernel(TailArgs t) {
     }
 }
 
+// kept out of line: inlined, its 32 loads in flight change how the compiler schedules the combine loop below (the
+// 32-row batch became three drained groups instead of a sliding window of 12; 10 -> 20 us for the launch)
+__device__ __attribute__((noinline)) void tail_loss_sum(const float* x, int64_t n, float* out, float* red) {
+    fixed_sum<256>(x, n, out, red);
+}
+
 template <int V, int LPR, int KIND>
 __global__ __launch_bounds__(256) void bpr_tail_combine_kernel(TailArgs t) {
     t.p.opt = resolve(t.p.opt);
@@ -811,7 +820,15 @@ __global__ __launch_bounds__(256) void bpr_tail_combine_kernel(TailArgs t) {
     const int k = t.p.k;
     const int cpr = k / V;
     const int nlong = t.p.hdr[1], split = t.p.hdr[3];
-    for (int l = blockIdx.x * SPB + sub; l < nlong; l += gridDim.x * SPB) {
+    // the step's loss (dr_sum_f32's order and bits) rides along as block 0 instead of a launch of its own after this one
+    __shared__ float red[1024];
+    const int first = t.loss_out ? 1 : 0;
+    if (first && blockIdx.x == 0) {
+        tail_loss_sum(t.loss_b, t.loss_n, t.loss_out, red);
+        return;
+    }
+    const int nblk = gridDim.x - first;
+    for (int l = (blockIdx.x - first) * SPB + sub; l < nlong; l += nblk * SPB) {
         const int s = t.p.long_seg[l];
         const SegArgs& a = (s < split) ? t.p : t.q;
         const uint32_t r = (uint32_t)a.uniq[s] - a.id_lo;
@@ -876,17 +893,17 @@ static void launch_tail(const TailArgs& t, int64_t n, hipStream_t st) {
     // work items <= n / DR_SEG_CHUNK + n / LONG_SEG (long blocks) + n / 2 (multi rows)
     const int64_t items = n / DR_SEG_CHUNK + n / LONG_SEG + n / 2 + 1;
     const int64_t blocks = (items + SPB - 1) / SPB;
-    const int cgrid = grid_for(n / LONG_SEG + 1, 1, SPB);
+    const int cgrid = grid_for(n / LONG_SEG + 1, 1, SPB) + (t.loss_out ? 1 : 0);
     if (t.p.kind == DR_OPT_ADAM) {
         DR_LAUNCH_NAMED("bpr_tail_kernel", (bpr_tail_kernel<V, LPR, DR_OPT_ADAM>),
                         dim3(grid_resident(bpr_tail_kernel<V, LPR, DR_OPT_ADAM>, blocks)), dim3(256), 0, st, t);
-        if (n > LONG_SEG)
+        if (n > LONG_SEG || t.loss_out)
             DR_LAUNCH_NAMED("bpr_tail_combine_kernel", (bpr_tail_combine_kernel<V, LPR, DR_OPT_ADAM>), dim3(cgrid), dim3(256),
                             0, st, t);
     } else {
         DR_LAUNCH_NAMED("bpr_tail_kernel", (bpr_tail_kernel<V, LPR, KIND_ANY>),
                         dim3(grid_resident(bpr_tail_kernel<V, LPR, KIND_ANY>, blocks)), dim3(256), 0, st, t);
-        if (n > LONG_SEG)
+        if (n > LONG_SEG || t.loss_out)
             DR_LAUNCH_NAMED("bpr_tail_combine_kernel", (bpr_tail_combine_kernel<V, LPR, KIND_ANY>), dim3(cgrid), dim3(256), 0,
                             st, t);
     }
@@ -1279,7 +1296,7 @@ int seg_launch(float* table, float* slot0, float* slot1, int64_t rows, int k, co
 // The combined plan of the batch (plan_build_bpr, fused) must be in `plan`; stash / coefQ as in bpr_step_impl.
 int bpr_tail_launch(float* P, float* Ps0, float* Ps1, int64_t nu, float* Q, float* Qs0, float* Qs1, int64_t ni, int k,
                     int64_t B, const float* stash, const float* coefQ, void* plan, int64_t plan_bytes,
-                    const dr_opt_params* opt, hipStream_t st) {
+                    const dr_opt_params* opt, hipStream_t st, const float* loss_b, float* loss_out) {
     const int64_t n = 3 * B;
     PlanLayout L;
     if (plan_layout(n, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
@@ -1295,6 +1312,9 @@ int bpr_tail_launch(float* P, float* Ps0, float* Ps1, int64_t nu, float* Q, floa
     if (rc != DR_OK) return rc;
     t.multi = (const int4*)(base + L.multi);
     t.long_cnt = (int32_t*)(base + L.long_cnt);
+    t.loss_b = loss_b;
+    t.loss_out = loss_out;
+    t.loss_n = B;
     RowShape s = row_shape(k);
     bool ok = false;
 #define DR_T(V_, L_)                          \
