@@ -115,7 +115,8 @@ def main():
 
     # Adam's bias-corrected step size lives on the device (dr_adam_tick_f32, TF's beta-power variables), so a
     # captured step keeps the exact per-step arithmetic when it is replayed
-    adam_state = K.AdamState(1e-3, 0.9, 0.999, device) if adam else None
+    # (--graph: one fixed scalar, ticked by a launch inside the captured step; eager: the next 16 step sizes per launch)
+    adam_state = K.AdamState(1e-3, 0.9, 0.999, device, ahead=1 if args.graph else 16) if adam else None
 
     def opt_for(step):
         b1p, b2p = 0.9 ** step, 0.999 ** step
@@ -156,6 +157,7 @@ def main():
             u, i, j = batches[b]
             if adam:
                 adam_state.tick()
+                opt_dev.alpha_dev = adam_state.alpha.data_ptr()
             if not pipelined:
                 return K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b])
             cur = torch.cuda.current_stream()
@@ -357,7 +359,16 @@ def live_kernel_profile(K, run_step, n_steps):
     cap = 4096
     names = C.create_string_buffer(1 << 18)
     ms = (C.c_float * cap)()
-    n = lib.dr_profile_collect(names, len(names), ms, cap)
+    tl = os.environ.get("DR_TIMELINE")          # file to write "start_us duration_us kernel" lines to (diagnostics)
+    if tl:
+        st_ms = (C.c_float * cap)()
+        n = lib.dr_profile_collect_timeline(names, len(names), C.cast(ms, C.c_void_p), C.cast(st_ms, C.c_void_p), cap)
+        if n > 0:
+            with open(tl, "a") as f:
+                for nm, a, d in zip(names.value.decode().split("\n")[:n], list(st_ms)[:n], list(ms)[:n]):
+                    f.write("%10.1f %8.1f %s\n" % (a * 1e3, d * 1e3, nm))
+    else:
+        n = lib.dr_profile_collect(names, len(names), ms, cap)
     if n < 0:
         raise RuntimeError("dr_profile_collect failed")
     acc = {}

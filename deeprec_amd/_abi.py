@@ -66,6 +66,7 @@ SIGNATURES = {
     "dr_score_matrix_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _i32, _p, _p, _i64, _p]),
     "dr_init_normal_f32": (_i32, [_p, _i64, C.c_uint64, _f, C.c_uint64, _p]),
     "dr_adam_tick_f32": (_i32, [_p, _f, _f, _f, _p]),
+    "dr_adam_tick_many_f32": (_i32, [_p, _f, _f, _f, _p, _i32, _p]),
     "dr_sum_f32": (_i32, [_p, _i64, _p, _p]),
     "dr_sample_negatives_i32": (_i32, [_p, _p, _p, _i64, _i32, _i64, _i64, _i64, C.c_uint64, C.c_uint64, _p, _p]),
     "dr_sample_negatives_excl_i32": (_i32, [_p, _i64, _i32, _i32, _i64, _i64, C.c_uint64, C.c_uint64, _p, _p]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "dr_seq_dot_loss_f32": (_i32, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _i32, _i32, _f, _p, _p, _p, _p, _p]),
     "dr_profile_enable": (_i32, [_i32]),
     "dr_profile_collect": (_i32, [C.c_char_p, _i64, C.POINTER(C.c_float), _i32]),
+    "dr_profile_collect_timeline": (_i32, [C.c_char_p, _i64, _p, _p, _i32]),
 }
 
 

@@ -64,7 +64,28 @@ __global__ void adam_tick_kernel(float* state, float lr, float beta1, float beta
     state[1] = b2p;
     state[2] = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
 }
+// n ticks by one thread (the same three operations per tick, in order): alphas[t] = the step size after tick t
+__global__ void adam_tick_many_kernel(float* state, float lr, float beta1, float beta2, float* alphas, int n) {
+    float b1p = state[0], b2p = state[1], a = state[2];
+    for (int t = 0; t < n; ++t) {
+        b1p = b1p * beta1;
+        b2p = b2p * beta2;
+        a = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+        alphas[t] = a;
+    }
+    state[0] = b1p;
+    state[1] = b2p;
+    state[2] = a;
+}
 }  // namespace dr
+
+extern "C" int32_t dr_adam_tick_many_f32(float* state, float lr, float beta1, float beta2, float* alphas, int32_t n,
+                                         void* stream) {
+    DR_REQUIRE(state != nullptr && alphas != nullptr && n >= 1, "dr_adam_tick_many_f32: bad arguments");
+    DR_LAUNCH(dr::adam_tick_many_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, lr, beta1, beta2, alphas, n);
+    DR_CHECK_LAUNCH("dr_adam_tick_many_f32");
+    return DR_OK;
+}
 
 extern "C" int32_t dr_adam_tick_f32(float* state, float lr, float beta1, float beta2, void* stream) {
     DR_REQUIRE(state != nullptr, "dr_adam_tick_f32: state is NULL");
@@ -129,7 +150,16 @@ extern "C" int32_t dr_profile_enable(int32_t on) {
     return DR_OK;
 }
 
+static int32_t profile_collect(char* names, int64_t names_bytes, float* ms, float* start_ms, int32_t cap);
 extern "C" int32_t dr_profile_collect(char* names, int64_t names_bytes, float* ms, int32_t cap) {
+    return profile_collect(names, names_bytes, ms, nullptr, cap);
+}
+extern "C" int32_t dr_profile_collect_timeline(char* names, int64_t names_bytes, float* ms, float* start_ms,
+                                               int32_t cap) {
+    DR_REQUIRE(start_ms != nullptr, "dr_profile_collect_timeline: start_ms is NULL");
+    return profile_collect(names, names_bytes, ms, start_ms, cap);
+}
+static int32_t profile_collect(char* names, int64_t names_bytes, float* ms, float* start_ms, int32_t cap) {
     DR_REQUIRE(names && names_bytes > 0 && ms && cap >= 0, "dr_profile_collect: bad arguments");
     int n = 0;
     int64_t off = 0;
@@ -144,6 +174,11 @@ extern "C" int32_t dr_profile_collect(char* names, int64_t names_bytes, float* m
         off += len;
         names[off++] = '\n';
         names[off] = 0;
+        if (start_ms) {
+            float t0 = 0.0f;
+            (void)hipEventElapsedTime(&t0, dr::g_prof[0].e0, r.e0);
+            start_ms[n] = t0;
+        }
         ms[n++] = t;
     }
     dr::g_prof_n = 0;

@@ -76,14 +76,34 @@ def opt_params(kind, lr=0.0, alpha=0.0, beta1=0.9, beta2=0.999, eps=1e-8, rho=0.
 
 
 class AdamState:
-    """Device-side beta-power state (dr_adam_tick_f32): tick() once per step, pass .alpha to opt_params."""
+    """Device-side beta-power state (dr_adam_tick_f32): tick() once per step, pass .alpha to opt_params.
 
-    def __init__(self, lr, beta1=0.9, beta2=0.999, device="cuda:0"):
+    ahead = 1: .alpha is one fixed device scalar (what a captured graph needs).  ahead = n > 1 (eager step loops): one
+    launch computes the next n step sizes (dr_adam_tick_many_f32, the same bits) and .alpha moves through them, so
+    build the opt_params (or set its alpha_dev) after every tick()."""
+
+    def __init__(self, lr, beta1=0.9, beta2=0.999, device="cuda:0", ahead=1):
         self.lr, self.beta1, self.beta2 = float(lr), float(beta1), float(beta2)
         self.state = torch.tensor([1.0, 1.0, 0.0, 0.0], dtype=torch.float32, device=device)
         self.alpha = self.state[2:3]
+        self.ahead = int(ahead)
+        if self.ahead > 1:
+            # two halves: the kernels of the last steps of one half may still be reading it while the next is written
+            self._ring = torch.zeros(2 * self.ahead, dtype=torch.float32, device=device)
+            self._half, self._i = 1, self.ahead
 
     def tick(self):
+        if self.ahead > 1:
+            if self._i == self.ahead:
+                self._half ^= 1
+                self._i = 0
+                check(_abi.lib().dr_adam_tick_many_f32(_ptr(self.state), self.lr, self.beta1, self.beta2,
+                                                       self._ring.data_ptr() + 4 * self._half * self.ahead, self.ahead,
+                                                       _stream()), "dr_adam_tick_many_f32")
+            o = self._half * self.ahead + self._i
+            self.alpha = self._ring[o:o + 1]
+            self._i += 1
+            return
         check(_abi.lib().dr_adam_tick_f32(_ptr(self.state), self.lr, self.beta1, self.beta2, _stream()),
               "dr_adam_tick_f32")
 

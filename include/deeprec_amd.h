@@ -310,6 +310,12 @@ int32_t dr_init_normal_f32(float* w, int64_t count, uint64_t seed, float stddev,
  * AdamOptimizer._finish): state[0] *= beta1, state[1] *= beta2 (fp32 running products, initialise to 1),
  * state[2] = lr * sqrt(1 - state[1]) / (1 - state[0]).  Point dr_opt_params.alpha_dev at &state[2]. */
 int32_t dr_adam_tick_f32(float* state, float lr, float beta1, float beta2, void* stream);
+/* n ticks in one launch (same operations, same bits as n calls of dr_adam_tick_f32): alphas[t] = state[2] after tick
+ * t + 1, the state ends where n single ticks would leave it.  An eager step loop points dr_opt_params.alpha_dev at
+ * alphas[t] for its t-th step and pays one tiny launch per n steps instead of one per step; a captured graph keeps
+ * dr_adam_tick_f32 (fixed address). */
+int32_t dr_adam_tick_many_f32(float* state, float lr, float beta1, float beta2, float* alphas, int32_t n,
+                              void* stream);
 /* Fixed-order sum of x[0..n) into out[0] (deterministic loss reduction). */
 int32_t dr_sum_f32(const float* x, int64_t n, float* out, void* stream);
 
@@ -481,6 +487,9 @@ int32_t dr_bpr_item_grads_f32(const float* P, int64_t rows, int32_t k, const int
  * clears the list.  bench.py's `roofline` comes from these numbers. */
 int32_t dr_profile_enable(int32_t on);
 int32_t dr_profile_collect(char* names, int64_t names_bytes, float* ms, int32_t cap);
+/* The same, plus start_ms[i] = start of launch i relative to the start of the first recorded launch (GPU clock): where
+ * the time between a step's kernels goes, without a profiler attached (tools/step_timeline.py). */
+int32_t dr_profile_collect_timeline(char* names, int64_t names_bytes, float* ms, float* start_ms, int32_t cap);
 
 #ifdef __cplusplus
 }

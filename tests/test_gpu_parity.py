@@ -92,6 +92,28 @@ def test_init_normal_matches_oracle(dev):
     assert np.array_equal(N(w), co.init_normal(100_003, 1234, 0.01))
 
 
+def test_adam_state_tick_and_tick_ahead(dev):
+    """dr_adam_tick_f32 = TF's beta-power variables in fp32 ([TF-ext] AdamOptimizer._finish / _apply_sparse's lr_t; the
+    arithmetic is restated here in numpy float32, parity with TensorFlow itself unpinned); dr_adam_tick_many_f32 gives the
+    same bits n steps at a time."""
+    from deeprec_amd import kernels as K
+    f = np.float32
+    lr, b1, b2 = f(1e-3), f(0.9), f(0.999)
+    one, ring = K.AdamState(lr, b1, b2, dev), K.AdamState(lr, b1, b2, dev, ahead=4)
+    b1p, b2p = f(1.0), f(1.0)
+    for t in range(11):
+        one.tick()
+        ring.tick()
+        b1p, b2p = f(b1p * b1), f(b2p * b2)
+        want = f(f(lr * np.sqrt(f(f(1.0) - b2p))) / f(f(1.0) - b1p))
+        got = N(one.alpha)[0]
+        assert got.tobytes() == want.tobytes(), (t, got, want)
+        assert N(ring.alpha)[0].tobytes() == want.tobytes(), t
+    ring.tick()                                  # the 12th tick ends a block of 4: the states agree again
+    one.tick()
+    assert np.array_equal(N(one.state)[:3], N(ring.state)[:3])
+
+
 # ------------------------------------------------------------------ K2
 @pytest.mark.parametrize("n,rows", [(0, 10), (1, 1), (2, 5), (300, 7), (3072, 2625), (4095, 100000), (4096, 3), (4097, 50),
                                     (5000, 37), (20000, 100000)])
