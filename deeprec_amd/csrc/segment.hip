@@ -166,6 +166,85 @@ __global__ __launch_bounds__(256) void plan_finalize_kernel(const uint32_t* __re
     }
 }
 
+// ---- run boundaries of the sorted keys in TWO launches (heads + rocPRIM scan [2 - 3 launches] + finalize were five) ----
+// plan_count_kernel: heads per tile of PLAN_TILE keys; plan_segments_kernel: every tile adds the counts of the tiles
+// before it (at most PLAN_MAX_TILES ints), scans its own keys in order and writes uniq / seg_start / hdr -- the same
+// values as plan_heads_kernel + exclusive_scan + plan_finalize_kernel.  No workgroup waits for another one.
+constexpr int PLAN_TILE = 4096;          // 256 threads x 16 consecutive keys
+constexpr int PLAN_MAX_TILES = 1024;     // above 4 M keys: the rocPRIM scan
+
+__global__ __launch_bounds__(256) void plan_count_kernel(const uint32_t* __restrict__ sk, int64_t n,
+                                                         int32_t* __restrict__ tile_heads) {
+    __shared__ int32_t red[4];
+    const int64_t base = (int64_t)blockIdx.x * PLAN_TILE;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < PLAN_TILE / 256; ++q) {
+        const int64_t e = base + q * 256 + threadIdx.x;
+        if (e < n) c += (e == 0 || sk[e] != sk[e - 1]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_heads[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void plan_segments_kernel(const uint32_t* __restrict__ sk, int64_t n,
+                                                            const int32_t* __restrict__ tile_heads,
+                                                            int32_t* __restrict__ uniq, int32_t* __restrict__ seg_start,
+                                                            int32_t* __restrict__ hdr, uint32_t split_key) {
+    __shared__ int32_t red[4];
+    __shared__ int32_t wtot[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // segments that start in earlier tiles
+    int before = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) before += tile_heads[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 0) red[wave] = before;
+    // this thread's 16 consecutive keys (and the key before them)
+    constexpr int PER = PLAN_TILE / 256;
+    const int64_t e0 = (int64_t)blockIdx.x * PLAN_TILE + (int64_t)tid * PER;
+    uint32_t key[PER + 1];
+    key[0] = (e0 > 0 && e0 - 1 < n) ? sk[e0 - 1] : 0u;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) key[q + 1] = (e0 + q < n) ? sk[e0 + q] : 0u;
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (e0 + q < n && (e0 + q == 0 || key[q + 1] != key[q])) ++mine;
+    // exclusive scan of `mine` over the 256 threads
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int seg = red[0] + red[1] + red[2] + red[3] + incl - mine;
+    for (int w = 0; w < wave; ++w) seg += wtot[w];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int64_t e = e0 + q;
+        if (e >= n) break;
+        const bool head = (e == 0 || key[q + 1] != key[q]);
+        if (head) {
+            uniq[seg] = (int32_t)key[q + 1];
+            seg_start[seg] = (int32_t)e;
+            // hdr[3]: first segment whose key is >= split_key (two tables sorted as one list)
+            if (key[q + 1] >= split_key && (e == 0 || key[q] < split_key)) hdr[3] = seg;
+            ++seg;
+        }
+        if (e == n - 1) {      // seg = number of segments now
+            hdr[0] = seg;
+            seg_start[seg] = (int32_t)n;
+            if (key[q + 1] < split_key) hdr[3] = seg;
+        }
+    }
+}
+
 // combined key list of one BPR batch: [u ; num_user + i ; num_user + j], invalid ids -> sentinel num_user + num_item
 __global__ __launch_bounds__(256) void plan_keys_bpr_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
                                                             const int32_t* __restrict__ j, int64_t B, int64_t nu,
@@ -1091,14 +1170,24 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
     size_t tb = (size_t)L.temp_bytes;
     DR_HIP((rocprim::radix_sort_pairs<PlanSortConfig>(base + L.temp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n,
                                                       0u, end_bit, st, false)));
-    DR_LAUNCH(plan_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, flags);
-    DR_CHECK_LAUNCH("plan_heads_kernel");
-    tb = (size_t)L.temp_bytes;
-    DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, segidx, (int32_t)0, (size_t)n,
-                                                             rocprim::plus<int32_t>(), st, false)));
-    DR_LAUNCH(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start, hdr,
-              split_key);
-    DR_CHECK_LAUNCH("plan_finalize_kernel");
+    const int64_t tiles = (n + PLAN_TILE - 1) / PLAN_TILE;
+    static const bool rocprim_scan = getenv("DR_PLAN_ROCPRIM_SCAN") != nullptr;
+    if (tiles <= PLAN_MAX_TILES && !rocprim_scan) {
+        DR_LAUNCH(plan_count_kernel, dim3((unsigned)tiles), dim3(256), 0, st, keys_out, n, flags);
+        DR_CHECK_LAUNCH("plan_count_kernel");
+        DR_LAUNCH(plan_segments_kernel, dim3((unsigned)tiles), dim3(256), 0, st, keys_out, n, (const int32_t*)flags, uniq,
+                  seg_start, hdr, split_key);
+        DR_CHECK_LAUNCH("plan_segments_kernel");
+    } else {
+        DR_LAUNCH(plan_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, flags);
+        DR_CHECK_LAUNCH("plan_heads_kernel");
+        tb = (size_t)L.temp_bytes;
+        DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, segidx, (int32_t)0, (size_t)n,
+                                                                 rocprim::plus<int32_t>(), st, false)));
+        DR_LAUNCH(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start, hdr,
+                  split_key);
+        DR_CHECK_LAUNCH("plan_finalize_kernel");
+    }
     if (n >= 2) {
         DR_LAUNCH(plan_long_kernel, dim3(grid), dim3(256), 0, st, seg_start, (const int32_t*)uniq, hdr, (int32_t*)(base + L.long_seg),
                   (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int4*)(base + L.multi),
