@@ -10,6 +10,13 @@
 
 namespace dr {
 
+// The view sort (4 * world * B keys, 262 144 at world 1 with the C4 batch) with rocPRIM's default configuration is a block
+// sort plus SIXTEEN merge launches (8 passes of partition + merge-path above 200 k keys).  4096 keys per block sort and
+// the one-kernel odd-even merge up to 1 M keys: 6 passes, 7 launches -- the sharded step is bound by its launch count.
+using RouteSortConfig = rocprim::radix_sort_config<rocprim::default_config,
+                                                   rocprim::merge_sort_config<512, 1024, 4, 128, 128, 4, (1u << 20)>,
+                                                   rocprim::default_config, 1024 * 1024>;
+
 struct RouteLayout {
     int64_t keys_in, keys_out, vals_in, vals_out, flags, segidx, temp, temp_bytes, total;
 };
@@ -36,7 +43,7 @@ static int route_layout(int64_t n, RouteLayout* L) {   // pure function of n; th
 static int route_layout_compute(int64_t n, RouteLayout* L) {
     size_t t_sort = 0, t_scan = 0;
     const int64_t nn = n > 0 ? n : 1;
-    hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, int32_t*, int32_t*>(
+    hipError_t e = rocprim::radix_sort_pairs<RouteSortConfig, uint32_t*, uint32_t*, int32_t*, int32_t*>(
         nullptr, t_sort, nullptr, nullptr, nullptr, nullptr, (size_t)nn, 0, 32, 0, false);
     if (e != hipSuccess) return -1;
     e = rocprim::exclusive_scan<rocprim::default_config, int32_t*, int32_t*, int32_t, rocprim::plus<int32_t>>(
@@ -103,6 +110,11 @@ __device__ __forceinline__ bool view_entry(const ViewArgs& a, int64_t x, uint32_
     *key = (view ? a.sentinel + 1u : 0u) + (mine ? major * a.rpo + item / (uint32_t)a.W : a.sentinel);
     *u_out = (int32_t)uu;
     return mine;
+}
+
+__global__ void view_zero_kernel(unsigned long long* __restrict__ counts, int n, int32_t* __restrict__ last_flag) {
+    for (int t = threadIdx.x; t < n; t += blockDim.x) counts[t] = 0ull;
+    if (threadIdx.x == 0) *last_flag = 0;
 }
 
 // keys + values of the 4 W B list entries; counts[4 W + 2] = samples (of the GLOBAL batch) with an id out of range
@@ -246,8 +258,10 @@ extern "C" int32_t dr_route_views_i32(const int32_t* ids, int32_t world, int64_t
                MAX_WORLD);
     DR_REQUIRE(counts != nullptr, "dr_route_views_i32: counts is NULL");
     hipStream_t st = (hipStream_t)stream;
-    DR_HIP(hipMemsetAsync(counts, 0, (size_t)(4 * world + 3) * 8, st));
-    if (B == 0) return DR_OK;
+    if (B == 0) {
+        DR_HIP(hipMemsetAsync(counts, 0, (size_t)(4 * world + 3) * 8, st));
+        return DR_OK;
+    }
     DR_REQUIRE(ids && u_loc && rows && inv && order && perm && uniq, "dr_route_views_i32: NULL pointer");
     const int64_t WB = (int64_t)world * B, m = 4 * WB;
     RouteLayout L;
@@ -275,12 +289,14 @@ extern "C" int32_t dr_route_views_i32(const int32_t* ids, int32_t world, int64_t
     a.rpo = (uint32_t)rows_per_owner;
     a.sentinel = (uint32_t)world * (uint32_t)rows_per_owner;
     const int grid = grid_for(m, 256);
-    // the compacted canonical index needs its own buffer next to the segment index: it lives in keys_in after the sort
+    // counts and the scan's extra entry start at zero: one small launch (two hipMemsetAsync calls cost more on the host)
+    DR_LAUNCH(view_zero_kernel, dim3(1), dim3(256), 0, st, (unsigned long long*)counts, 4 * world + 3, flags + m);
+    DR_CHECK_LAUNCH("view_zero_kernel");
     DR_LAUNCH(view_keys_kernel, dim3(grid), dim3(256), 0, st, a, kin, vin, flags, (unsigned long long*)counts);
     DR_CHECK_LAUNCH("view_keys_kernel");
-    DR_HIP(hipMemsetAsync(flags + m, 0, 4, st));
-    DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, kin, kout, vin, vout, (size_t)m, 0u,
+    DR_HIP((rocprim::radix_sort_pairs<RouteSortConfig>(base + L.temp, tb, kin, kout, vin, vout, (size_t)m, 0u,
                                                                bits_for(2ull * a.sentinel + 1ull), st, false)));
+    // the compacted canonical index needs its own buffer next to the segment index: it lives in keys_in after the sort
     int32_t* cidx = (int32_t*)kin;                  // keys_in is free now (m * 4 bytes + the 256-byte pad holds entry m)
     tb = (size_t)L.temp_bytes;
     DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, cidx, (int32_t)0, (size_t)(m + 1),

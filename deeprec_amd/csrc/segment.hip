@@ -48,6 +48,27 @@ using PlanSortConfig = rocprim::radix_sort_config<rocprim::default_config,
                                                   rocprim::default_config, 1024 * 1024>;
 #endif
 
+// rocPRIM's merge sort leaves the result in the input buffers after an odd number of merge passes and copies it over
+// (two more launches).  Twice the keys per block sort is one pass less: chosen when that makes the count even (131 072
+// keys: 5 passes + 2 copies -> 4 passes).
+using PlanSortConfig2 = rocprim::radix_sort_config<rocprim::default_config,
+                                                   rocprim::merge_sort_config<512, 1024, 8, 128, 128, 4>,
+                                                   rocprim::default_config, 1024 * 1024>;
+static int merge_passes(int64_t n, int64_t per_block) {
+    int64_t runs = (n + per_block - 1) / per_block;
+    int p = 0;
+    while ((1ll << p) < runs) ++p;
+    return p;
+}
+static bool plan_sort_wide(int64_t n) {
+#if DR_PLAN_SORT_IPT == 4
+    static const bool off = getenv("DR_PLAN_SORT_NARROW") != nullptr;
+    return !off && n < 1024 * 1024 && (merge_passes(n, 4096) & 1) && !(merge_passes(n, 8192) & 1);
+#else
+    return false;
+#endif
+}
+
 static int plan_layout_compute(int64_t n, int k_max, PlanLayout* L, char* err);
 // The layout is a pure function of (n, k_max), and every plan / update / size call asks for it: the two rocPRIM
 // temporary-storage queries inside were a measurable part of the host time of a step that issues ~50 short launches
@@ -83,6 +104,16 @@ static int plan_layout_compute(int64_t n, int k_max, PlanLayout* L, char* err) {
     if (e != hipSuccess) {
         snprintf(err, 512, "rocprim radix_sort size query: %s", hipGetErrorString(e));
         return -1;
+    }
+    if (plan_sort_wide(nn)) {
+        size_t t2 = 0;
+        e = rocprim::radix_sort_pairs<PlanSortConfig2, uint32_t*, uint32_t*, int32_t*, int32_t*>(
+            nullptr, t2, nullptr, nullptr, nullptr, nullptr, (size_t)nn, 0, 32, 0, false);
+        if (e != hipSuccess) {
+            snprintf(err, 512, "rocprim radix_sort size query: %s", hipGetErrorString(e));
+            return -1;
+        }
+        if (t2 > t_sort) t_sort = t2;
     }
     e = rocprim::exclusive_scan<rocprim::default_config, int32_t*, int32_t*, int32_t, rocprim::plus<int32_t>>(
         nullptr, t_scan, nullptr, nullptr, 0, (size_t)nn, rocprim::plus<int32_t>(), 0, false);
@@ -1168,8 +1199,12 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
     }
     const int grid = grid_for(n, 256);
     size_t tb = (size_t)L.temp_bytes;
-    DR_HIP((rocprim::radix_sort_pairs<PlanSortConfig>(base + L.temp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n,
-                                                      0u, end_bit, st, false)));
+    if (plan_sort_wide(n))
+        DR_HIP((rocprim::radix_sort_pairs<PlanSortConfig2>(base + L.temp, tb, keys_in, keys_out, vals_in, vals_out,
+                                                           (size_t)n, 0u, end_bit, st, false)));
+    else
+        DR_HIP((rocprim::radix_sort_pairs<PlanSortConfig>(base + L.temp, tb, keys_in, keys_out, vals_in, vals_out,
+                                                          (size_t)n, 0u, end_bit, st, false)));
     const int64_t tiles = (n + PLAN_TILE - 1) / PLAN_TILE;
     static const bool rocprim_scan = getenv("DR_PLAN_ROCPRIM_SCAN") != nullptr;
     if (tiles <= PLAN_MAX_TILES && !rocprim_scan) {
