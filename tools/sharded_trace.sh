@@ -2,5 +2,5 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/shard_trace -o s -- python $R/bench.py --sharded --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/shard_trace.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/shard_trace -o s -- python $R/bench.py --sharded --steps 200 --warmup 5 --no-cpu-baseline > $R/gpurun_out/shard_trace.log 2>&1
 ls $R/gpurun_out/shard_trace
