@@ -1004,15 +1004,24 @@ static void launch_tail(const TailArgs& t, int64_t n, hipStream_t st) {
     const int64_t items = n / DR_SEG_CHUNK + n / LONG_SEG + n / 2 + 1;
     const int64_t blocks = (items + SPB - 1) / SPB;
     const int cgrid = grid_for(n / LONG_SEG + 1, 1, SPB) + (t.loss_out ? 1 : 0);
+    // Twice the resident blocks: a sub-wave then takes ONE work item (a 32-contribution block sum is 2 - 3 times a
+    // short row) and the hardware hands the remaining blocks to whichever CU is free; with exactly the resident count
+    // the sub-waves that start with a block sum also get a row each: 21.0 -> 18.9 us (x4 and x16: 18.8, 18.7).  Fetching
+    // a block's 32 indices / coefficients one per lane and passing them across lanes was measured too: + 2.7 us.
+    static const int mult = getenv("DR_TAIL_GRID_MULT") ? atoi(getenv("DR_TAIL_GRID_MULT")) : 2;
+    auto tail_grid = [&](int resident) {
+        const int64_t g = (int64_t)resident * mult;
+        return (int)(g < blocks ? g : blocks);
+    };
     if (t.p.kind == DR_OPT_ADAM) {
         DR_LAUNCH_NAMED("bpr_tail_kernel", (bpr_tail_kernel<V, LPR, DR_OPT_ADAM>),
-                        dim3(grid_resident(bpr_tail_kernel<V, LPR, DR_OPT_ADAM>, blocks)), dim3(256), 0, st, t);
+                        dim3(tail_grid(grid_resident(bpr_tail_kernel<V, LPR, DR_OPT_ADAM>, blocks))), dim3(256), 0, st, t);
         if (n > LONG_SEG || t.loss_out)
             DR_LAUNCH_NAMED("bpr_tail_combine_kernel", (bpr_tail_combine_kernel<V, LPR, DR_OPT_ADAM>), dim3(cgrid), dim3(256),
                             0, st, t);
     } else {
         DR_LAUNCH_NAMED("bpr_tail_kernel", (bpr_tail_kernel<V, LPR, KIND_ANY>),
-                        dim3(grid_resident(bpr_tail_kernel<V, LPR, KIND_ANY>, blocks)), dim3(256), 0, st, t);
+                        dim3(tail_grid(grid_resident(bpr_tail_kernel<V, LPR, KIND_ANY>, blocks))), dim3(256), 0, st, t);
         if (n > LONG_SEG || t.loss_out)
             DR_LAUNCH_NAMED("bpr_tail_combine_kernel", (bpr_tail_combine_kernel<V, LPR, KIND_ANY>), dim3(cgrid), dim3(256), 0,
                             st, t);
