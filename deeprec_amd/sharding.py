@@ -218,7 +218,7 @@ class ShardedBpr:
         if self.side is None:
             return self._route_begin(u, i, j)
         ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream())
+        ready.record()                              # on the caller's current stream (no Stream object built: ~8 us each)
         self.side.wait_event(ready)
         for t in (u, i, j):
             t.record_stream(self.side)              # the caller may drop the batch right after step()
@@ -250,7 +250,7 @@ class ShardedBpr:
         self._pending = None
         begun = self._begin_ahead(*next_batch) if next_batch is not None else None
         if rt.ready is not None:
-            torch.cuda.current_stream().wait_event(rt.ready)
+            rt.ready.wait()                         # the caller's current stream waits for the route's side-stream work
         loss = self.run(rt, opt)
         if begun is not None:
             self._pending = self._finish_ahead(begun)
