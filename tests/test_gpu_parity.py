@@ -116,8 +116,10 @@ def test_adam_state_tick_and_tick_ahead(dev):
 
 # ------------------------------------------------------------------ K2
 @pytest.mark.parametrize("n,rows", [(0, 10), (1, 1), (2, 5), (300, 7), (3072, 2625), (4095, 100000), (4096, 3), (4097, 50),
-                                    (5000, 37), (20000, 100000)])
-def test_segment_plan(dev, n, rows):      # n <= 4096: the single-workgroup plan kernel; above: rocPRIM path
+                                    (5000, 37), (20000, 100000), (8192, 3), (8193, 1), (12289, 4000), (131072, 9),
+                                    (131073, 500000)])
+def test_segment_plan(dev, n, rows):      # n <= 4096: the single-workgroup plan kernel; above: rocPRIM sort + tile kernels
+    # (runs that cross the 4096-key tiles of plan_count / plan_segments; 131 072 keys take the wide block sort)
     from deeprec_amd import kernels as K
     rng = np.random.default_rng(n)
     ids = rng.integers(0, rows, n).astype(np.int32)
