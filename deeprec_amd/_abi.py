@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeeprec_amd.so")
+# DEEPREC_AMD_LIB: another build of the SAME library (tools/ A/B runs: `make experiments`, ablation builds); a path that
+# does not exist fails loudly like the default one
+LIB_PATH = os.environ.get("DEEPREC_AMD_LIB") or os.path.join(_HERE, "libdeeprec_amd.so")
 
 
 class OptParams(C.Structure):

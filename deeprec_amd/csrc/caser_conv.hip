@@ -730,7 +730,7 @@ extern "C" int32_t dr_caser_hconv_direct_f32(const float* e, const float* W, con
                "dr_caser_hconv_direct_f32: NULL / misaligned pointer");
     const int64_t nsg = (B + 15) / 16;
     const int npairs = (L + 1) / 2;
-    if (d % 32 == 0 && getenv("DR_HCONV_16COL") == nullptr) {    // 32-column chunks, two height pairs per workgroup
+    if (d % 32 == 0 && DR_EXP_ENV("DR_HCONV_16COL") == nullptr) {    // 32-column chunks, two height pairs per workgroup
         const int nduo = (npairs + 1) / 2;
         DR_REQUIRE(nsg * nduo < (1ll << 31) - 1, "dr_caser_hconv_direct_f32: grid too large");
         size_t lds2 = (size_t)L * 2048;

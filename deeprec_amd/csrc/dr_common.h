@@ -67,13 +67,21 @@ extern thread_local bool g_no_side_streams;
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Experiment switches (grid caps, ablations) exist only in -DDR_EXPERIMENTS builds (`make experiments`, used by tools/):
+// the release library reads no environment variable, so a stray one cannot change which kernels run.
+#ifdef DR_EXPERIMENTS
+#define DR_EXP_ENV(name) getenv(name)
+#else
+#define DR_EXP_ENV(name) ((const char*)nullptr)
+#endif
+
 // Memory-bound launches: cap the grid at CUs * blocks-per-CU and grid-stride the rest
 // (256 CUs on MI355X; 8 blocks of 256 threads per CU = full 32 waves/CU).
 static inline int grid_for(int64_t work_items, int block, int items_per_block_iter = 1) {
     int64_t per = (int64_t)block * items_per_block_iter;
     int64_t g = (work_items + per - 1) / per;
     if (g < 1) g = 1;
-    static const int64_t cap = getenv("DR_GRID_CAP") ? atoll(getenv("DR_GRID_CAP")) : 256 * 8;
+    static const int64_t cap = DR_EXP_ENV("DR_GRID_CAP") ? atoll(DR_EXP_ENV("DR_GRID_CAP")) : 256 * 8;
     return (int)(g > cap ? cap : g);
 }
 
@@ -84,7 +92,7 @@ static inline int grid_for(int64_t work_items, int block, int items_per_block_it
 int occupancy_blocks(const void* kernel, int block);  // abi.hip
 template <typename KernelT>
 static inline int grid_resident(KernelT kernel, int64_t work_blocks, int block = 256) {
-    static const bool off = getenv("DR_GRID_CAP") != nullptr;
+    static const bool off = DR_EXP_ENV("DR_GRID_CAP") != nullptr;
     int cap = off ? 0 : occupancy_blocks(reinterpret_cast<const void*>(kernel), block);
     if (cap <= 0) return grid_for(work_blocks, 1, 1);
     if (work_blocks < 1) work_blocks = 1;

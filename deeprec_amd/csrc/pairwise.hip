@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void bpr_forward_kernel(const float* __restric
 // its one gradient contribution, L2 and the optimizer and writes it back (solo[] flags from the plan).  Saves the
 // stash round trip, the second read of the row and of its source row, and most of the two segment launches.
 // Arithmetic = the segment kernel's for a one-contribution segment (tot = 0 + c; tot = 0 + tot; apply_row), so the
-// tables stay bit-identical to the unfused step.  stash row b = pre-step P[u_b] when the user row is solo (its item
-// rows' remaining contributions read it there, SegArgs.src2), else g * (q_i - q_j) as before.
+// tables stay bit-identical to the unfused step.  stash row b = g * (q_i - q_j) for shared user rows (the tail sums them),
+// stash row B + b = pre-step P[u_b] whenever one of the sample's item rows is shared (the tail reads it, SegArgs.src2).
 struct FusedTables {
     SegArgs p, q;  // only table / slots / rows / k / kind / opt are used (apply_row)
 };
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, 
             coef2[b] = g;
             coef2[B + b] = -g;
         }
-        const bool need_p_old = su && !(si && sj);  // some contribution of this sample goes through the segment path
+        const bool need_p_old = vu && !(si && sj);  // some item-side contribution of this sample goes through the tail
         for (int c = lane; c < cpr; c += LPR) {
             float pu[V], qi[V], qj[V];
             if (c == lane && ok) {
@@ -226,11 +226,12 @@ __global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, 
 #pragma unroll
             for (int x = 0; x < V; ++x) d[x] = g * (ok ? (qi[x] - qj[x]) : 0.0f);
             const bool pre = ok && c == lane;  // rows and slots of this column are in registers
+            // pre-step copy of the user row for the tail pass (its item-side contributions never read P in place)
+            if (need_p_old) vstore<V>(stash + (B + b) * k + c * V, pu);
             if (su) {
                 float tot[V];
 #pragma unroll
                 for (int x = 0; x < V; ++x) tot[x] = 0.0f + (0.0f + d[x]);
-                if (need_p_old) vstore<V>(stash + b * k + c * V, pu);
                 if (pre) {
                     float w[V];
 #pragma unroll
@@ -241,8 +242,6 @@ __global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, 
                 }
             } else {
                 vstore<V>(stash + b * k + c * V, d);
-                // a shared user row is updated by the tail pass: its item-side contributions read this pre-step copy
-                if (vu && !(si && sj)) vstore<V>(stash + (B + b) * k + c * V, pu);
             }
             if (si) {
                 float tot[V];
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, 
 // The same for k == V * LPR (every lane owns exactly one vector column; k = 128, 64, 32, ...): no column loops and no
 // reload paths, every row and optimizer slot of the sample is requested in one round, and the per-id validity makes
 // the update path uniform (an invalid sample contributes zero rows to its valid solo rows, like the segment path).
-// stash rows [B, 2B): pre-step P[u_b] of samples whose user row is NOT solo (read by their item-side contributions).
+// stash rows [B, 2B): pre-step P[u_b] of samples with a shared item row (read by their item-side contributions).
 template <int V, int LPR, int KIND>
 __global__ __launch_bounds__(256) void bpr_forward_update_1col_kernel(FusedTables t, const int32_t* __restrict__ u,
                                                                       const int32_t* __restrict__ i,
@@ -362,15 +361,14 @@ __global__ __launch_bounds__(256) void bpr_forward_update_1col_kernel(FusedTable
             for (int x = 0; x < V; ++x) tot[x] = vu ? (0.0f + (0.0f + ng * pu[x])) : 0.0f;
             apply_row_loaded<V, KIND>(t.q, (uint32_t)ij, lane, tot, qj, mj, vj2);
         }
+        // pre-step copy of the user row (stash row B + b) for the tail pass: item-side contributions never read P in place
+        if (vu && !(si && sj)) vstore<V>(stash + (B + b) * k + lane * V, pu);
         if (su) {
-            if (!(si && sj)) vstore<V>(stash + b * k + lane * V, pu);  // pre-step copy for the segment path
 #pragma unroll
             for (int x = 0; x < V; ++x) tot[x] = 0.0f + (0.0f + d[x]);
             apply_row_loaded<V, KIND>(t.p, (uint32_t)iu, lane, tot, pu, mu, vu2);
         } else {
-            vstore<V>(stash + b * k + lane * V, d);
-            // a shared user row is updated by the tail pass: its item-side contributions read this pre-step copy
-            if (vu && !(si && sj)) vstore<V>(stash + (B + b) * k + lane * V, pu);
+            vstore<V>(stash + b * k + lane * V, d);   // a shared user row: summed and applied by the tail pass
         }
     }
 }
@@ -406,7 +404,7 @@ struct SideStream {
 };
 static SideStream* side_stream() {
     static thread_local SideStream side[32];
-    static const bool off = getenv("DR_NO_OVERLAP") != nullptr;
+    static const bool off = DR_EXP_ENV("DR_NO_OVERLAP") != nullptr;
     if (off || g_no_side_streams) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
@@ -721,7 +719,7 @@ static int bpr_forward_update(float* P, float* Ps0, float* Ps1, int64_t num_user
     t.q.table = Q; t.q.slot0 = Qs0; t.q.slot1 = Qs1; t.q.rows = num_item;
     RowShape s = row_shape(k);
     bool ok = false;
-    static const int64_t fwd_grid = getenv("DR_FWD_GRID") ? atoll(getenv("DR_FWD_GRID")) : 0;  // experiment knob
+    static const int64_t fwd_grid = DR_EXP_ENV("DR_FWD_GRID") ? atoll(DR_EXP_ENV("DR_FWD_GRID")) : 0;
 #define DR_F(V_, L_)                                                                                                  \
     if (!ok && s.V == V_ && s.LPR == L_) {                                                                            \
         int64_t wb_ = (B + 256 / L_ - 1) / (256 / L_);                                                                 \
@@ -805,8 +803,7 @@ static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_use
     }
     // The planned step in a sparse regulariser mode is FUSED: the forward kernel applies every single-contribution row
     // itself (flags in the plan), the segment kernels only see rows with two or more contributions.
-    static const bool no_fuse = getenv("DR_NO_FUSE") != nullptr;
-    const bool fused = mode != 0 && reg_mode != DR_REG_DENSE && !no_fuse;
+    const bool fused = mode != 0 && reg_mode != DR_REG_DENSE;
     if (mode != 1 && B > 0) {  // enqueued first: the host then feeds the helper stream while this runs
         if (fused && mode == 2) {
             const unsigned char* solo = plan_solo_flags(base + L.planA, 3 * B, k);
@@ -826,8 +823,7 @@ static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_use
         }
         if (mode == 1) return DR_OK;
     }
-    static const bool no_tail = getenv("DR_NO_TAIL") != nullptr;
-    if (any && fused && mode == 2 && !no_tail) {
+    if (any && fused && mode == 2) {
         // every row with two or more contributions, both tables, one launch (bpr_tail_kernel): rows of the two tables
         // are disjoint, Q-side sources are pre-step P rows (in place for non-solo users, the stash copy for solo ones)
         // and P-side sources are stash rows, none of which this launch writes
@@ -841,10 +837,10 @@ static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_use
         if (side) DR_HIP(hipStreamWaitEvent(st, side->q_ready, 0));
         rc = table_apply(Q, Qslot0, Qslot1, num_item, k, 3 * B, P, num_user, nullptr, coefQ, base + L.planA,
                          L.plan_bytesA, (float*)(base + L.gdenseQ), opt, st, true,
-                         SegSel{(uint32_t)num_user, 2, (int)B}, 2 * B, fused ? stash : nullptr, fused);
+                         SegSel{(uint32_t)num_user, 2, (int)B}, 2 * B);
         if (rc != DR_OK) return rc;
         rc = table_apply(P, Pslot0, Pslot1, num_user, k, 3 * B, stash, B, nullptr, nullptr, base + L.planA,
-                         L.plan_bytesA, (float*)(base + L.gdenseP), opt, st, true, SegSel{0, 1, 0}, B, nullptr, fused);
+                         L.plan_bytesA, (float*)(base + L.gdenseP), opt, st, true, SegSel{0, 1, 0}, B);
         if (rc != DR_OK) return rc;
     }
     if (loss_out) return dr_sum_f32(loss_b, B, loss_out, st);

@@ -1714,7 +1714,7 @@ extern "C" int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu
     // k <= 128: the register-selection kernel serves calls in which no user has more than one held-out item; the
     // general kernel the others.  Which it is is a device-side fact (the target CSR), so both are enqueued and
     // the one not in charge returns at once.
-    const bool t1 = a.k <= 128 && n_targets <= Nu && getenv("DR_SCORE_NO_T1") == nullptr;
+    const bool t1 = a.k <= 128 && n_targets <= Nu && DR_EXP_ENV("DR_SCORE_NO_T1") == nullptr;
     if (t1) {
         int32_t* flag = (int32_t*)(base + L.mode);
         DR_HIP(hipMemsetAsync(flag, 0, 4, st));

@@ -7,6 +7,7 @@
 // to oracle/ref_ops.py:segment_sums.  The sort / scan of the plan use rocPRIM device primitives
 // (radix_sort_pairs, exclusive_scan); everything that touches table rows is hand-written.
 #include "dr_common.h"
+#include "dr_lsd_sort.h"
 #include "dr_segment.h"
 
 #include <cstring>
@@ -20,7 +21,7 @@ namespace dr {
 // ---------------------------------------------------------------------------------------
 struct PlanLayout {
     int64_t hdr, keys_in, keys_out, vals_in, vals_out, flags, segidx, uniq, seg_start, temp, temp_bytes, total;
-    int64_t long_seg, long_cb, part_owner, partials, partial_rows, msrc, mcoef, solo, multi, long_cnt;
+    int64_t long_seg, long_cb, part_owner, partials, partial_rows, msrc, mcoef, solo, multi, long_cnt, lsd;
 };
 
 // Segments with more than LONG_SEG contributions ("long": anything beyond the few-duplicates common case) are
@@ -28,46 +29,16 @@ struct PlanLayout {
 // own sub-wave (block partials parked in the plan's scratch), seg_long_combine_kernel adds a segment's
 // partials in block order and applies the update -- the same blocked position order, in parallel.
 constexpr int LONG_SEG = 4;
+constexpr int PLAN_TILE = 4096;          // run boundaries: 256 threads x 16 consecutive keys per workgroup
+constexpr int PLAN_MAX_TILES = 1024;     // above 4 M keys: the rocPRIM scan
 
-// rocPRIM below 1 M items: a block sort + merge passes (9 launches for the 196 608 keys of a C4 batch with the default
-// configuration).  Forcing Onesweep (merge-sort limit 0) was measured and is slower here: plan 116 us instead of 75 us,
-// fused step 0.270 ms instead of 0.228 ms.
-// The merge-sort path with 4096 keys per block sort (1024 threads x 4): 48 sorted runs and 6 merge passes for the 196 608
-// keys of a C4 batch instead of 192 runs and 8 passes -- the plan is a chain of short dependent launches, so fewer
-// passes is what counts.  Measured, plan alone / pipelined step: default 91.1 / 177.3 us, 4 per thread 88.3 / 175.5,
-// 8 per thread (5 passes, but a slower block sort) 96.9 / 175.2.  Forcing Onesweep was measured in round 1: slower.
-// (DR_PLAN_SORT_IPT chooses the items per thread at build time; 0 = rocPRIM's default configuration.)
-#ifndef DR_PLAN_SORT_IPT
-#define DR_PLAN_SORT_IPT 4
+// Lists up to DR_LSD_MAX_N keys are sorted by the library's own LSD sort (dr_lsd_sort.h: 2 launches per 8-bit digit);
+// rocPRIM's device sort (Onesweep at that size) stays for longer ones: 4 M keys 0.28 ms against 0.34 - 0.48 ms.
+// (Rounds 1 - 2 used rocPRIM throughout: a 4096-key block sort plus 6 merge launches for the 196 608 keys of a C4
+// batch, 56 us of a 76 - 100 us plan.)
+#ifndef DR_LSD_MAX_N
+#define DR_LSD_MAX_N (1ll << 20)
 #endif
-#if DR_PLAN_SORT_IPT == 0
-using PlanSortConfig = rocprim::default_config;
-#else
-using PlanSortConfig = rocprim::radix_sort_config<rocprim::default_config,
-                                                  rocprim::merge_sort_config<512, 1024, DR_PLAN_SORT_IPT, 128, 128, 4>,
-                                                  rocprim::default_config, 1024 * 1024>;
-#endif
-
-// rocPRIM's merge sort leaves the result in the input buffers after an odd number of merge passes and copies it over
-// (two more launches).  Twice the keys per block sort is one pass less: chosen when that makes the count even (131 072
-// keys: 5 passes + 2 copies -> 4 passes).
-using PlanSortConfig2 = rocprim::radix_sort_config<rocprim::default_config,
-                                                   rocprim::merge_sort_config<512, 1024, 8, 128, 128, 4>,
-                                                   rocprim::default_config, 1024 * 1024>;
-static int merge_passes(int64_t n, int64_t per_block) {
-    int64_t runs = (n + per_block - 1) / per_block;
-    int p = 0;
-    while ((1ll << p) < runs) ++p;
-    return p;
-}
-static bool plan_sort_wide(int64_t n) {
-#if DR_PLAN_SORT_IPT == 4
-    static const bool off = getenv("DR_PLAN_SORT_NARROW") != nullptr;
-    return !off && n < 1024 * 1024 && (merge_passes(n, 4096) & 1) && !(merge_passes(n, 8192) & 1);
-#else
-    return false;
-#endif
-}
 
 static int plan_layout_compute(int64_t n, int k_max, PlanLayout* L, char* err);
 // The layout is a pure function of (n, k_max), and every plan / update / size call asks for it: the two rocPRIM
@@ -99,27 +70,22 @@ static int plan_layout(int64_t n, int k_max, PlanLayout* L, char* err) {
 static int plan_layout_compute(int64_t n, int k_max, PlanLayout* L, char* err) {
     size_t t_sort = 0, t_scan = 0;
     int64_t nn = n > 0 ? n : 1;
-    hipError_t e = rocprim::radix_sort_pairs<PlanSortConfig, uint32_t*, uint32_t*, int32_t*, int32_t*>(
-        nullptr, t_sort, nullptr, nullptr, nullptr, nullptr, (size_t)nn, 0, 32, 0, false);
-    if (e != hipSuccess) {
-        snprintf(err, 512, "rocprim radix_sort size query: %s", hipGetErrorString(e));
-        return -1;
-    }
-    if (plan_sort_wide(nn)) {
-        size_t t2 = 0;
-        e = rocprim::radix_sort_pairs<PlanSortConfig2, uint32_t*, uint32_t*, int32_t*, int32_t*>(
-            nullptr, t2, nullptr, nullptr, nullptr, nullptr, (size_t)nn, 0, 32, 0, false);
+    hipError_t e = hipSuccess;
+    if (nn > DR_LSD_MAX_N) {
+        e = rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, int32_t*, int32_t*>(
+            nullptr, t_sort, nullptr, nullptr, nullptr, nullptr, (size_t)nn, 0, 32, 0, false);
         if (e != hipSuccess) {
             snprintf(err, 512, "rocprim radix_sort size query: %s", hipGetErrorString(e));
             return -1;
         }
-        if (t2 > t_sort) t_sort = t2;
     }
-    e = rocprim::exclusive_scan<rocprim::default_config, int32_t*, int32_t*, int32_t, rocprim::plus<int32_t>>(
-        nullptr, t_scan, nullptr, nullptr, 0, (size_t)nn, rocprim::plus<int32_t>(), 0, false);
-    if (e != hipSuccess) {
-        snprintf(err, 512, "rocprim exclusive_scan size query: %s", hipGetErrorString(e));
-        return -1;
+    if ((nn + PLAN_TILE - 1) / PLAN_TILE > PLAN_MAX_TILES) {
+        e = rocprim::exclusive_scan<rocprim::default_config, int32_t*, int32_t*, int32_t, rocprim::plus<int32_t>>(
+            nullptr, t_scan, nullptr, nullptr, 0, (size_t)nn, rocprim::plus<int32_t>(), 0, false);
+        if (e != hipSuccess) {
+            snprintf(err, 512, "rocprim exclusive_scan size query: %s", hipGetErrorString(e));
+            return -1;
+        }
     }
     int64_t off = 0;
     auto take = [&](int64_t bytes) {
@@ -149,24 +115,24 @@ static int plan_layout_compute(int64_t n, int k_max, PlanLayout* L, char* err) {
     L->multi = take((nn / 2 + 1) * 16);  // int4 {segment, key, first sorted position, length} of every segment with
                                          // 2 .. LONG_SEG contributions (arbitrary order), count in hdr[4]
     L->long_cnt = take(max_long * 4);    // blocks of a long segment summed so far (bpr_tail_kernel), zero between uses
+    L->lsd = take(lsd_scratch_bytes(nn));  // tile histograms (+ column prefixes) of the plan's LSD sort
     L->partials = take(L->partial_rows * (int64_t)(k_max > 0 ? k_max : 1) * 4);
     L->total = off;
     return 0;
 }
 
-template <typename IdT>
-__global__ __launch_bounds__(256) void plan_keys_kernel(const IdT* __restrict__ ids, int64_t n, int64_t rows,
-                                                        uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
-                                                        int32_t* __restrict__ hdr) {
+// key / position lists of a key source, materialised (only the rocPRIM path above LSD_MAX_N keys needs them)
+template <class Src>
+__global__ __launch_bounds__(256) void plan_keys_kernel(Src src, int64_t n, uint32_t* __restrict__ keys,
+                                                        int32_t* __restrict__ vals, int32_t* __restrict__ hdr) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr[1] = 0;  // number of long segments
         hdr[2] = 0;  // partial rows handed out
         hdr[4] = 0;  // number of segments with 2 .. LONG_SEG contributions
     }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        int64_t id = (int64_t)ids[e];
-        keys[e] = (id < 0 || id >= rows) ? (uint32_t)rows : (uint32_t)id;  // out-of-range -> sentinel `rows`
-        vals[e] = (int32_t)e;
+        keys[e] = src.key(e);
+        vals[e] = src.val(e);
     }
 }
 
@@ -201,8 +167,6 @@ __global__ __launch_bounds__(256) void plan_finalize_kernel(const uint32_t* __re
 // plan_count_kernel: heads per tile of PLAN_TILE keys; plan_segments_kernel: every tile adds the counts of the tiles
 // before it (at most PLAN_MAX_TILES ints), scans its own keys in order and writes uniq / seg_start / hdr -- the same
 // values as plan_heads_kernel + exclusive_scan + plan_finalize_kernel.  No workgroup waits for another one.
-constexpr int PLAN_TILE = 4096;          // 256 threads x 16 consecutive keys
-constexpr int PLAN_MAX_TILES = 1024;     // above 4 M keys: the rocPRIM scan
 
 __global__ __launch_bounds__(256) void plan_count_kernel(const uint32_t* __restrict__ sk, int64_t n,
                                                          int32_t* __restrict__ tile_heads) {
@@ -276,37 +240,20 @@ __global__ __launch_bounds__(256) void plan_segments_kernel(const uint32_t* __re
     }
 }
 
-// combined key list of one BPR batch: [u ; num_user + i ; num_user + j], invalid ids -> sentinel num_user + num_item
-__global__ __launch_bounds__(256) void plan_keys_bpr_kernel(const int32_t* __restrict__ u, const int32_t* __restrict__ i,
-                                                            const int32_t* __restrict__ j, int64_t B, int64_t nu,
-                                                            int64_t ni, uint32_t* __restrict__ keys,
-                                                            int32_t* __restrict__ vals, int32_t* __restrict__ hdr) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        hdr[1] = 0;
-        hdr[2] = 0;
-        hdr[4] = 0;
-    }
-    const uint32_t sentinel = (uint32_t)(nu + ni);
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < 3 * B; e += (int64_t)gridDim.x * 256) {
-        uint32_t key;
-        if (e < B) {
-            const int64_t id = u[e];
-            key = (id < 0 || id >= nu) ? sentinel : (uint32_t)id;
-        } else {
-            const int64_t id = (e < 2 * B) ? i[e - B] : j[e - 2 * B];
-            key = (id < 0 || id >= ni) ? sentinel : (uint32_t)(nu + id);
-        }
-        keys[e] = key;
-        vals[e] = (int32_t)e;
-    }
-}
-
 // source rows of the sorted contributions of a BPR batch: position p < B reads stash row p (P side), position
 // B + x reads the user row u[x mod B] (Q side: g_b * p_u).
 // fused (the planned step in a sparse regulariser mode): rows whose segment holds ONE contribution are updated by
-// the forward kernel itself.  solo[p] marks those positions; a Q-side contribution of a sample whose user row is
-// solo must not read P in place (the forward kernel has already updated it) but the pre-step copy the forward kernel
-// leaves in stash row x: source index nu + x (SegArgs.src2).
+// the forward kernel itself.  solo[p] marks those positions; a Q-side contribution must then not read P in place (the
+// forward kernel may already have updated the row) but the pre-step copy the forward kernel leaves in stash row
+// B + x: source index nu + B + x (SegArgs.src2).
+__device__ __forceinline__ int32_t bpr_msrc(int p, const int32_t* __restrict__ u, int64_t B, int64_t nu, int fused) {
+    if (p < B) return p;
+    const int64_t x = (p - B < B) ? p - B : p - 2 * B;
+    const int64_t id = u[x];
+    if (id < 0 || id >= nu) return -1;
+    return fused ? (int32_t)(nu + B + x) : (int32_t)id;
+}
+
 __global__ __launch_bounds__(256) void bpr_meta_kernel(const int32_t* __restrict__ sorted_pos,
                                                        const uint32_t* __restrict__ sk,
                                                        const int32_t* __restrict__ u, int64_t B, int64_t nu, int64_t ni,
@@ -320,27 +267,171 @@ __global__ __launch_bounds__(256) void bpr_meta_kernel(const int32_t* __restrict
             const uint32_t key = sk[y];
             solo[p] = (key != sentinel && (y == 0 || sk[y - 1] != key) && (y == n - 1 || sk[y + 1] != key)) ? 1 : 0;
         }
-        if (p < B) {
-            msrc[y] = p;
-        } else {
-            const int64_t x = (p - B) % B;
-            const int64_t id = u[x];
-            msrc[y] = (id >= 0 && id < nu) ? (int32_t)id : -1;
-        }
+        msrc[y] = bpr_msrc(p, u, B, nu, fused);
     }
 }
 
-// second pass of the fused variant (needs every solo flag): Q-side contributions read the stash copy of the user row
-__global__ __launch_bounds__(256) void bpr_meta_solo_kernel(const int32_t* __restrict__ sorted_pos, int64_t B, int64_t nu,
-                                                            const unsigned char* __restrict__ solo,
-                                                            int32_t* __restrict__ msrc) {
-    for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < 3 * B; y += (int64_t)gridDim.x * 256) {
-        const int p = sorted_pos[y];
-        if (p >= B) {
-            // the pre-step user row of sample x: stash row x when the user row is solo, stash row B + x otherwise
-            // (the forward kernel leaves it there) -- never P in place, so the item side may run beside the user side
-            const int64_t x = (p - B) % B;
-            if (msrc[y] >= 0) msrc[y] = (int32_t)(nu + (solo[x] ? x : B + x));
+// ---- everything the fused BPR step needs from the sorted keys, in ONE launch --------------------------------------
+// (was: run heads per tile, segment table, long / multi lists, source rows, solo flags, solo fix-up = six launches.)
+// The fused step never walks a segment table: the forward kernel wants a solo flag per position, the tail kernel a
+// descriptor per row with 2 .. LONG_SEG contributions and a block list per longer row.  All of that follows from a
+// key's neighbours in the sorted list, so no global scan is needed: the "segment index" of a row is simply the sorted
+// position of its first contribution (uniq / seg_start are written at that index for the long rows only, and hdr[3],
+// the first item-side segment, is the number of user-side keys).  A workgroup owns 1024 consecutive sorted positions
+// (keys in LDS); a long run that leaves the workgroup's range finds its end by a galloping search in memory.
+constexpr int FIN_TILE = 1024;
+__global__ __launch_bounds__(256) void bpr_finish_kernel(const uint32_t* __restrict__ sk, const int32_t* __restrict__ spos,
+                                                         int64_t n, const int32_t* __restrict__ u, int64_t B, int64_t nu,
+                                                         int64_t ni, int32_t* __restrict__ hdr, int32_t* __restrict__ uniq,
+                                                         int32_t* __restrict__ seg_start, int32_t* __restrict__ long_seg,
+                                                         int32_t* __restrict__ long_cb, int32_t* __restrict__ long_cnt,
+                                                         int32_t* __restrict__ part_owner, int4* __restrict__ multi,
+                                                         int32_t* __restrict__ msrc, unsigned char* __restrict__ solo) {
+    __shared__ uint32_t lk[FIN_TILE];
+    __shared__ int wcnt[4];
+    __shared__ int blk_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * FIN_TILE;
+    const int64_t end = (base + FIN_TILE < n) ? base + FIN_TILE : n;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;  // never a key (keys <= nu + ni < 2^32 - 2)
+#pragma unroll
+    for (int q = 0; q < FIN_TILE / 256; ++q) {
+        const int64_t e = base + q * 256 + tid;
+        lk[q * 256 + tid] = e < n ? sk[e] : NONE;
+    }
+    __syncthreads();
+    auto keyat = [&](int64_t y) -> uint32_t {
+        if (y >= base && y < base + FIN_TILE) return lk[y - base];
+        return (y >= 0 && y < n) ? sk[y] : NONE;
+    };
+    const uint32_t sentinel = (uint32_t)(nu + ni), split = (uint32_t)nu;
+    // this thread's four consecutive sorted positions
+    int n_multi = 0, m_len[2] = {0, 0};
+    int64_t m_y[2] = {0, 0};
+    uint32_t m_key[2] = {0u, 0u};
+    int64_t l_y = -1, l_end = 0;
+    uint32_t l_key = 0u;
+    const int64_t y0 = base + (int64_t)tid * 4;
+    uint32_t prev = keyat(y0 - 1);
+    int4 ms = make_int4(-1, -1, -1, -1);
+    int32_t pp[4] = {0, 0, 0, 0};
+    if (y0 + 3 < n) {
+        const int4 t = *reinterpret_cast<const int4*>(spos + y0);
+        pp[0] = t.x; pp[1] = t.y; pp[2] = t.z; pp[3] = t.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (y0 + q < n) pp[q] = spos[y0 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t y = y0 + q;
+        if (y >= n) break;
+        const uint32_t key = lk[tid * 4 + q];
+        const uint32_t next = keyat(y + 1);
+        const bool head = prev != key, last = next != key;
+        const int p = pp[q];
+        solo[p] = (key != sentinel && head && last) ? 1 : 0;
+        (&ms.x)[q] = bpr_msrc(p, u, B, nu, 1);
+        // hdr[3] = number of user-side keys = index of the first item-side segment (prev = NONE at y = 0)
+        if (key >= split && (prev < split || y == 0)) hdr[3] = (int32_t)y;
+        if (y == n - 1 && key < split) hdr[3] = (int32_t)n;
+        if (head && !last && key != sentinel) {
+            int len = 2;
+            if (keyat(y + 2) == key) {
+                len = 3;
+                if (keyat(y + 3) == key) {
+                    len = 4;
+                    if (keyat(y + 4) == key) len = 5;
+                }
+            }
+            if (len <= LONG_SEG) {
+                m_y[n_multi] = y;
+                m_key[n_multi] = key;
+                m_len[n_multi] = len;
+                ++n_multi;
+            } else {
+                // the run's end: inside this workgroup's range (binary search in LDS) or beyond it (gallop in memory)
+                int64_t lo, hi;
+                if (keyat(end - 1) != key) {
+                    lo = y + 5;
+                    hi = end - 1;
+                } else {
+                    lo = end;
+                    int64_t step = 32;
+                    while (lo + step <= n && sk[lo + step - 1] == key) {
+                        lo += step;
+                        step *= 2;
+                    }
+                    hi = (lo + step < n) ? lo + step : n;
+                }
+                while (lo < hi) {   // first index in [lo, hi] whose key differs (keys are sorted: it is larger)
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (keyat(mid) == key) lo = mid + 1;
+                    else hi = mid;
+                }
+                l_y = y;
+                l_end = lo;
+                l_key = key;
+            }
+        }
+        prev = key;
+    }
+    if (y0 + 3 < n) {
+        *reinterpret_cast<int4*>(msrc + y0) = ms;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (y0 + q < n) msrc[y0 + q] = (&ms.x)[q];
+    }
+    // descriptors of the rows with 2 .. LONG_SEG contributions: one reservation per workgroup
+    int incl = n_multi;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wcnt[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        const int t = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        blk_base = t ? atomicAdd(&hdr[4], t) : 0;
+    }
+    __syncthreads();
+    int slot = blk_base + incl - n_multi;
+    for (int w = 0; w < wave; ++w) slot += wcnt[w];
+    for (int x = 0; x < n_multi; ++x)
+        multi[slot + x] = make_int4((int)m_y[x], (int)m_key[x], (int)m_y[x], m_len[x]);
+    // long rows: a block list each; one reservation pair per wavefront that has any
+    const bool is_long = l_y >= 0;
+    const unsigned long long ml = __ballot(is_long);
+    if (ml) {
+        const int len = is_long ? (int)(l_end - l_y) : 0;
+        const int nch = is_long ? (len + DR_SEG_CHUNK - 1) / DR_SEG_CHUNK : 0;
+        int inc2 = nch;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc2, o, 64);
+            if (lane >= o) inc2 += v;
+        }
+        const int total = __shfl(inc2, 63, 64);
+        int l0 = 0, c0 = 0;
+        if (lane == 0) {
+            l0 = atomicAdd(&hdr[1], __popcll(ml));
+            c0 = atomicAdd(&hdr[2], total);
+        }
+        l0 = __shfl(l0, 0, 64);
+        c0 = __shfl(c0, 0, 64);
+        if (is_long) {
+            const int l = l0 + __popcll(ml & ((1ull << lane) - 1ull));
+            const int cb = c0 + inc2 - nch;
+            long_seg[l] = (int32_t)l_y;          // "segment index" = sorted position of the first contribution
+            long_cb[l] = cb;
+            long_cnt[l] = 0;
+            uniq[l_y] = (int32_t)l_key;
+            seg_start[l_y] = (int32_t)l_y;
+            seg_start[l_y + 1] = (int32_t)l_end; // l_y + 1 lies inside the run: never another row's index
+            for (int c = 0; c < nch; ++c) part_owner[cb + c] = l;
         }
     }
 }
@@ -452,8 +543,8 @@ __global__ __launch_bounds__(256) void plan_long_kernel(const int32_t* __restric
 // Same outputs as plan_finish (sorted positions, uniq, seg_start, hdr, long lists); the sort is stable, so they
 // are identical to the general path's.
 constexpr int SMALL_IPT = 4, SMALL_N = 1024 * SMALL_IPT;
-template <int SMALL_T>  // 256 threads serve lists of <= 1024 keys (fewer, cheaper barriers), 1024 threads <= 4096
-__global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __restrict__ keys_in, int n,
+template <int SMALL_T, class Src>  // 256 threads serve lists of <= 1024 keys (fewer, cheaper barriers), 1024 threads <= 4096
+__global__ __launch_bounds__(SMALL_T) void plan_small_kernel(Src src, int n,
                                                               unsigned end_bit, uint32_t split_key,
                                                               uint32_t* __restrict__ keys_out,
                                                               int32_t* __restrict__ vals_out,
@@ -480,7 +571,7 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(const uint32_t* __r
 #pragma unroll
     for (int q = 0; q < SMALL_IPT; ++q) {
         const int e = tid * SMALL_IPT + q;
-        key[q] = e < n ? keys_in[e] : pad;
+        key[q] = e < n ? src.key(e) : pad;
         val[q] = e;
     }
     Sort().sort(key, val, tmp.sort, 0u, end_bit);
@@ -557,8 +648,8 @@ hipStream_t seg_side_stream(hipStream_t main, hipEvent_t* fork, hipEvent_t* join
         hipEvent_t fork = nullptr, join = nullptr;
     };
     static thread_local Side side[32];
-    static const bool off = getenv("DR_NO_OVERLAP") != nullptr;
-    static const bool always = getenv("DR_OVERLAP") != nullptr;
+    static const bool off = DR_EXP_ENV("DR_NO_OVERLAP") != nullptr;
+    static const bool always = DR_EXP_ENV("DR_OVERLAP") != nullptr;
     int dev = 0;
     if (off || g_no_side_streams || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return main;
     if (!always) {
@@ -1008,7 +1099,7 @@ static void launch_tail(const TailArgs& t, int64_t n, hipStream_t st) {
     // short row) and the hardware hands the remaining blocks to whichever CU is free; with exactly the resident count
     // the sub-waves that start with a block sum also get a row each: 21.0 -> 18.9 us (x4 and x16: 18.8, 18.7).  Fetching
     // a block's 32 indices / coefficients one per lane and passing them across lanes was measured too: + 2.7 us.
-    static const int mult = getenv("DR_TAIL_GRID_MULT") ? atoi(getenv("DR_TAIL_GRID_MULT")) : 2;
+    static const int mult = DR_EXP_ENV("DR_TAIL_GRID_MULT") ? atoi(DR_EXP_ENV("DR_TAIL_GRID_MULT")) : 2;
     auto tail_grid = [&](int resident) {
         const int64_t g = (int64_t)resident * mult;
         return (int)(g < blocks ? g : blocks);
@@ -1180,8 +1271,11 @@ __global__ __launch_bounds__(256) void rownorm_clip_kernel(float* __restrict__ t
 using namespace dr;
 
 namespace dr {
-// shared tail of the plan builders: keys_in / vals_in are filled; sort, run boundaries, long-segment list
-static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_bit, uint32_t split_key, hipStream_t st) {
+// shared tail of the plan builders: stable sort of (key, position) and -- with `tables` -- run boundaries (uniq /
+// seg_start / hdr) and the long / multi lists; the fused BPR plan builds its own lists (bpr_finish_kernel)
+template <class Src>
+static int plan_finish(Src src, char* base, const PlanLayout& L, int64_t n, unsigned end_bit, uint32_t split_key,
+                       hipStream_t st, bool tables) {
     int32_t* hdr = (int32_t*)(base + L.hdr);
     uint32_t* keys_in = (uint32_t*)(base + L.keys_in);
     uint32_t* keys_out = (uint32_t*)(base + L.keys_out);
@@ -1191,15 +1285,14 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
     int32_t* segidx = (int32_t*)(base + L.segidx);
     int32_t* uniq = (int32_t*)(base + L.uniq);
     int32_t* seg_start = (int32_t*)(base + L.seg_start);
-    static const bool no_small = getenv("DR_NO_SMALL_PLAN") != nullptr;
-    if (n <= SMALL_N && !no_small) {
+    if (n <= SMALL_N) {
         if (n <= 256 * SMALL_IPT)
-            DR_LAUNCH(plan_small_kernel<256>, dim3(1), dim3(256), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
+            DR_LAUNCH((plan_small_kernel<256, Src>), dim3(1), dim3(256), 0, st, src, (int)n, end_bit,
                       split_key, keys_out, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
                       (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int4*)(base + L.multi),
                       (int32_t*)(base + L.long_cnt));
         else
-            DR_LAUNCH(plan_small_kernel<1024>, dim3(1), dim3(1024), 0, st, (const uint32_t*)keys_in, (int)n, end_bit,
+            DR_LAUNCH((plan_small_kernel<1024, Src>), dim3(1), dim3(1024), 0, st, src, (int)n, end_bit,
                       split_key, keys_out, vals_out, uniq, seg_start, hdr, (int32_t*)(base + L.long_seg),
                       (int32_t*)(base + L.long_cb), (int32_t*)(base + L.part_owner), (int4*)(base + L.multi),
                       (int32_t*)(base + L.long_cnt));
@@ -1207,16 +1300,19 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
         return DR_OK;
     }
     const int grid = grid_for(n, 256);
-    size_t tb = (size_t)L.temp_bytes;
-    if (plan_sort_wide(n))
-        DR_HIP((rocprim::radix_sort_pairs<PlanSortConfig2>(base + L.temp, tb, keys_in, keys_out, vals_in, vals_out,
-                                                           (size_t)n, 0u, end_bit, st, false)));
-    else
-        DR_HIP((rocprim::radix_sort_pairs<PlanSortConfig>(base + L.temp, tb, keys_in, keys_out, vals_in, vals_out,
-                                                          (size_t)n, 0u, end_bit, st, false)));
+    if (n <= DR_LSD_MAX_N) {
+        int rc = lsd_sort(src, n, end_bit, keys_in, vals_in, keys_out, vals_out, base + L.lsd, hdr, st);
+        if (rc != DR_OK) return rc;
+    } else {
+        DR_LAUNCH((plan_keys_kernel<Src>), dim3(grid), dim3(256), 0, st, src, n, keys_in, vals_in, hdr);
+        DR_CHECK_LAUNCH("plan_keys_kernel");
+        size_t tb = (size_t)L.temp_bytes;
+        DR_HIP((rocprim::radix_sort_pairs<rocprim::default_config>(base + L.temp, tb, keys_in, keys_out, vals_in, vals_out,
+                                                                   (size_t)n, 0u, end_bit, st, false)));
+    }
+    if (!tables) return DR_OK;
     const int64_t tiles = (n + PLAN_TILE - 1) / PLAN_TILE;
-    static const bool rocprim_scan = getenv("DR_PLAN_ROCPRIM_SCAN") != nullptr;
-    if (tiles <= PLAN_MAX_TILES && !rocprim_scan) {
+    if (tiles <= PLAN_MAX_TILES) {
         DR_LAUNCH(plan_count_kernel, dim3((unsigned)tiles), dim3(256), 0, st, keys_out, n, flags);
         DR_CHECK_LAUNCH("plan_count_kernel");
         DR_LAUNCH(plan_segments_kernel, dim3((unsigned)tiles), dim3(256), 0, st, keys_out, n, (const int32_t*)flags, uniq,
@@ -1225,7 +1321,7 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
     } else {
         DR_LAUNCH(plan_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, n, flags);
         DR_CHECK_LAUNCH("plan_heads_kernel");
-        tb = (size_t)L.temp_bytes;
+        size_t tb = (size_t)L.temp_bytes;
         DR_HIP((rocprim::exclusive_scan<rocprim::default_config>(base + L.temp, tb, flags, segidx, (int32_t)0, (size_t)n,
                                                                  rocprim::plus<int32_t>(), st, false)));
         DR_LAUNCH(plan_finalize_kernel, dim3(grid), dim3(256), 0, st, keys_out, flags, segidx, n, uniq, seg_start, hdr,
@@ -1242,7 +1338,8 @@ static int plan_finish(char* base, const PlanLayout& L, int64_t n, unsigned end_
 }
 
 // One plan for both tables of a BPR batch (3B contributions: [u ; i ; j], Q keys offset by num_user) plus the
-// source-row list of the sorted contributions.  Half the launches of two separate plans.
+// source-row list of the sorted contributions.  fused (the planned step): sort (2 x 2 launches) + bpr_finish_kernel;
+// lists of <= 4096 keys: the one-workgroup plan + bpr_meta_kernel.
 int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t B, int64_t nu, int64_t ni, void* plan,
                    int64_t plan_bytes, int k, hipStream_t st, bool fused) {
     const int64_t n = 3 * B;
@@ -1259,21 +1356,23 @@ int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t
         DR_CHECK_LAUNCH("bpr plan (empty)");
         return DR_OK;
     }
-    DR_LAUNCH(plan_keys_bpr_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, u, i, j, B, nu, ni,
-              (uint32_t*)(base + L.keys_in), (int32_t*)(base + L.vals_in), hdr);
-    DR_CHECK_LAUNCH("plan_keys_bpr_kernel");
     unsigned end_bit = 1;
     while (end_bit < 32 && ((uint64_t)(nu + ni) >> end_bit) != 0) ++end_bit;
-    int rc = plan_finish(base, L, n, end_bit, (uint32_t)nu, st);
+    const bool finish = fused && n > SMALL_N;
+    int rc = plan_finish(LsdBpr{u, i, j, B, nu, ni}, base, L, n, end_bit, (uint32_t)nu, st, !finish);
     if (rc != DR_OK) return rc;
+    if (finish) {
+        DR_LAUNCH_NAMED("bpr_finish_kernel", bpr_finish_kernel, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(256), 0,
+                        st, (const uint32_t*)(base + L.keys_out), (const int32_t*)(base + L.vals_out), n, u, B, nu, ni, hdr,
+                        (int32_t*)(base + L.uniq), (int32_t*)(base + L.seg_start), (int32_t*)(base + L.long_seg),
+                        (int32_t*)(base + L.long_cb), (int32_t*)(base + L.long_cnt), (int32_t*)(base + L.part_owner),
+                        (int4*)(base + L.multi), (int32_t*)(base + L.msrc), (unsigned char*)(base + L.solo));
+        DR_CHECK_LAUNCH("bpr_finish_kernel");
+        return DR_OK;
+    }
     DR_LAUNCH(bpr_meta_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int32_t*)(base + L.vals_out),
               (const uint32_t*)(base + L.keys_out), u, B, nu, ni, fused ? 1 : 0, (int32_t*)(base + L.msrc),
               (unsigned char*)(base + L.solo));
-    if (fused) {
-        DR_CHECK_LAUNCH("bpr_meta_kernel");
-        DR_LAUNCH(bpr_meta_solo_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, (const int32_t*)(base + L.vals_out), B, nu,
-                  (const unsigned char*)(base + L.solo), (int32_t*)(base + L.msrc));
-    }
     DR_CHECK_LAUNCH("bpr_meta_kernel");
     return DR_OK;
 }
@@ -1300,31 +1399,16 @@ extern "C" int32_t dr_segment_plan(const void* ids, int64_t n, int32_t id_bits, 
                 (long long)L.total);
     char* base = (char*)plan;
     hipStream_t st = (hipStream_t)stream;
-    int32_t* hdr = (int32_t*)(base + L.hdr);
-    uint32_t* keys_in = (uint32_t*)(base + L.keys_in);
-    uint32_t* keys_out = (uint32_t*)(base + L.keys_out);
-    int32_t* vals_in = (int32_t*)(base + L.vals_in);
-    int32_t* vals_out = (int32_t*)(base + L.vals_out);
-    int32_t* flags = (int32_t*)(base + L.flags);
-    int32_t* segidx = (int32_t*)(base + L.segidx);
-    int32_t* uniq = (int32_t*)(base + L.uniq);
-    int32_t* seg_start = (int32_t*)(base + L.seg_start);
     if (n == 0) {
-        DR_LAUNCH(plan_empty_kernel, dim3(1), dim3(1), 0, st, hdr, seg_start);
+        DR_LAUNCH(plan_empty_kernel, dim3(1), dim3(1), 0, st, (int32_t*)(base + L.hdr), (int32_t*)(base + L.seg_start));
         DR_CHECK_LAUNCH("dr_segment_plan(empty)");
         return DR_OK;
     }
-    int grid = grid_for(n, 256);
-    if (id_bits == 32)
-        DR_LAUNCH((plan_keys_kernel<int32_t>), dim3(grid), dim3(256), 0, st, (const int32_t*)ids, n, rows,
-                           keys_in, vals_in, hdr);
-    else
-        DR_LAUNCH((plan_keys_kernel<int64_t>), dim3(grid), dim3(256), 0, st, (const int64_t*)ids, n, rows,
-                           keys_in, vals_in, hdr);
-    DR_CHECK_LAUNCH("plan_keys_kernel");
     unsigned end_bit = 1;
     while (end_bit < 32 && ((uint64_t)rows >> end_bit) != 0) ++end_bit;  // enough bits for the sentinel `rows`
-    return plan_finish(base, L, n, end_bit, 0xFFFFFFFFu, st);
+    if (id_bits == 32)
+        return plan_finish(LsdIds<int32_t>{(const int32_t*)ids, rows}, base, L, n, end_bit, 0xFFFFFFFFu, st, true);
+    return plan_finish(LsdIds<int64_t>{(const int64_t*)ids, rows}, base, L, n, end_bit, 0xFFFFFFFFu, st, true);
 }
 
 extern "C" int32_t dr_segment_plan_view(void* plan, int64_t n, const int32_t** sorted_pos, const int32_t** uniq_ids,

@@ -117,9 +117,11 @@ def test_adam_state_tick_and_tick_ahead(dev):
 # ------------------------------------------------------------------ K2
 @pytest.mark.parametrize("n,rows", [(0, 10), (1, 1), (2, 5), (300, 7), (3072, 2625), (4095, 100000), (4096, 3), (4097, 50),
                                     (5000, 37), (20000, 100000), (8192, 3), (8193, 1), (12289, 4000), (131072, 9),
-                                    (131073, 500000)])
-def test_segment_plan(dev, n, rows):      # n <= 4096: the single-workgroup plan kernel; above: rocPRIM sort + tile kernels
-    # (runs that cross the 4096-key tiles of plan_count / plan_segments; 131 072 keys take the wide block sort)
+                                    (131073, 500000), (50000, 20_000_000), (4100, 2**31 - 2), (300_000, 11_000_000),
+                                    (262_144, 4095), (262_145, 4096), (600_000, 1000), (1_100_000, 70_000)])
+def test_segment_plan(dev, n, rows):      # n <= 4096: the single-workgroup plan kernel; above: the LSD sort + tile kernels
+    # (runs that cross the 2048-key tiles of the sort and the 4096-key tiles of plan_count / plan_segments; one to four 8-bit
+    # digits; more than 256 tiles: the column-scan launch; above 2^20 keys: rocPRIM; a ragged last tile)
     from deeprec_amd import kernels as K
     rng = np.random.default_rng(n)
     ids = rng.integers(0, rows, n).astype(np.int32)
