@@ -224,10 +224,11 @@ def main():
         # id-only routing of batch t+1 runs on a second stream / communicator while batch t's kernels execute
         trainer = sh.ShardedBpr(K, Pt, Qt)
         trainer.prefetch(*batches[0])
-        launch = "eager; routes (id exchanges, owners' segment plans) one batch ahead on a second stream"
+        trainer.prefetch(*batches[1])
+        launch = "eager; routes (id all-gather, the rank's lists and plan) two batches ahead on a second stream"
 
         def step(t):
-            return trainer.step(opt_for(t + 1), next_batch=batches[(t + 1) % len(batches)])
+            return trainer.step(opt_for(t + 1), next_batch=batches[(t + 2) % len(batches)])
 
     def barrier():
         if world > 1:

@@ -74,9 +74,13 @@ SIGNATURES = {
     "dr_sample_negatives_excl_i32": (_i32, [_p, _i64, _i32, _i32, _i64, _i64, C.c_uint64, C.c_uint64, _p, _p]),
     "dr_bucket_order_bytes": (_i64, [_i64]),
     "dr_bucket_order_i32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
-    "dr_route_bytes": (_i64, [_i64]),
-    "dr_route_views_i32": (_i32, [_p, _i32, _i64, _i32, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
-    "dr_bpr_item_grads_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p, _p]),
+    "dr_shard_bpr_bytes": (_i64, [_i32, _i64, _i32, _i64, _i64]),
+    "dr_shard_bpr_list": (_i32, [_i32, _i64, _i32, _i64, _i64, _p, _i32, C.POINTER(_p)]),
+    "dr_shard_bpr_route": (_i32, [_p, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _p, _i64, _p]),
+    "dr_shard_bpr_forward": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _p, _p, _optp,
+                                    _p, _i64, _p]),
+    "dr_shard_bpr_finish": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _p, _optp, _p,
+                                   _p, _i64, _p]),
     "dr_mlp_forward_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "dr_mlp_backward_f32": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "dr_tower_catalog_scores_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p]),

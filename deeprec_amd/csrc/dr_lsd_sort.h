@@ -88,19 +88,24 @@ struct LsdBpr {
 
 // ---- pass, launch 1: digit histogram of every tile --------------------------------------------------------------
 // zero3: three plan-header counters that have to start at zero ride along (NULL: none)
+// n_dev (may be NULL): the list length lives on the device (the launch is then sized for the capacity `n` and the
+// workgroups beyond the real length leave at once)
 template <class Src>
-__global__ __launch_bounds__(LSD_T) void lsd_hist_kernel(Src src, int64_t n, unsigned shift, uint32_t mask,
-                                                         uint16_t* __restrict__ hist, int32_t* __restrict__ zero3) {
+__global__ __launch_bounds__(LSD_T) void lsd_hist_kernel(Src src, int64_t n, const int32_t* __restrict__ n_dev,
+                                                         unsigned shift, uint32_t mask, uint16_t* __restrict__ hist,
+                                                         int32_t* __restrict__ zero3) {
     __shared__ int bins[LSD_BINS];
     const int tid = threadIdx.x;
+    if (n_dev) n = *n_dev;
     if (zero3 && blockIdx.x == 0 && tid == 0) {
         zero3[1] = 0;
         zero3[2] = 0;
         zero3[4] = 0;
     }
+    const int64_t base = (int64_t)blockIdx.x * LSD_TILE;
+    if (base >= n) return;   // block-uniform
     for (int d = tid; d < LSD_BINS; d += LSD_T) bins[d] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * LSD_TILE;
 #pragma unroll
     for (int q = 0; q < LSD_IPT; ++q) {
         const int64_t e = base + q * LSD_T + tid;
@@ -112,9 +117,11 @@ __global__ __launch_bounds__(LSD_T) void lsd_hist_kernel(Src src, int64_t n, uns
 
 // ---- (large lists) column prefixes of the tile histograms, once -------------------------------------------------
 static __global__ __launch_bounds__(256) void lsd_colscan_kernel(const uint16_t* __restrict__ hist, int ntiles,
+                                                          const int32_t* __restrict__ n_dev,
                                                           uint32_t* __restrict__ colpre, uint32_t* __restrict__ total) {
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= LSD_BINS) return;
+    if (n_dev) ntiles = (int)(((int64_t)*n_dev + LSD_TILE - 1) / LSD_TILE);
     uint32_t run = 0;
     int t = 0;
     for (; t + 8 <= ntiles; t += 8) {
@@ -136,7 +143,8 @@ static __global__ __launch_bounds__(256) void lsd_colscan_kernel(const uint16_t*
 
 // ---- pass, launch 2: ranked scatter -----------------------------------------------------------------------------
 template <class Src>
-__global__ __launch_bounds__(LSD_T) void lsd_scatter_kernel(Src src, int64_t n, unsigned shift, uint32_t mask,
+__global__ __launch_bounds__(LSD_T) void lsd_scatter_kernel(Src src, int64_t n, const int32_t* __restrict__ n_dev,
+                                                            unsigned shift, uint32_t mask,
                                                             unsigned bits, const uint16_t* __restrict__ hist, int ntiles,
                                                             const uint32_t* __restrict__ colpre,
                                                             const uint32_t* __restrict__ total,
@@ -155,6 +163,11 @@ __global__ __launch_bounds__(LSD_T) void lsd_scatter_kernel(Src src, int64_t n, 
     __shared__ uint16_t rstart[LSD_BINS];
     const int tid = threadIdx.x, tile = blockIdx.x;
     const int64_t base = (int64_t)tile * LSD_TILE;
+    if (n_dev) {
+        n = *n_dev;
+        ntiles = (int)((n + LSD_TILE - 1) / LSD_TILE);
+    }
+    if (base >= n) return;   // block-uniform
     const int nt = (n - base < LSD_TILE) ? (int)(n - base) : LSD_TILE;
     // the tile's keys, blocked: thread t holds list positions 4t .. 4t+3 of the tile, so that rank order is list order.
     // Keys beyond the list get the largest digit and the largest local indices: a stable sort leaves them last.
@@ -247,10 +260,11 @@ static inline unsigned lsd_passes(unsigned end_bit) { return end_bit <= LSD_BITS
 
 // Sort the n keys of `src` on bits [0, end_bit) (stable; payload = src.val).  The result lands in (keys_out, vals_out);
 // (keys_tmp, vals_tmp) is the other buffer pair of the ping-pong; scratch: lsd_scratch_bytes(n), 256-byte aligned.
-// zero3: see lsd_hist_kernel.  Launches: 2 per pass (3 above LSD_INLINE_TILES tiles).
+// zero3, n_dev: see lsd_hist_kernel (with n_dev, n is the capacity the launches are sized for).
+// Launches: 2 per pass (3 above LSD_INLINE_TILES tiles).
 template <class Src>
 static int lsd_sort(Src src, int64_t n, unsigned end_bit, uint32_t* keys_tmp, int32_t* vals_tmp, uint32_t* keys_out,
-                    int32_t* vals_out, void* scratch, int32_t* zero3, hipStream_t st) {
+                    int32_t* vals_out, void* scratch, int32_t* zero3, hipStream_t st, const int32_t* n_dev = nullptr) {
     if (n <= 0) return DR_OK;
     DR_REQUIRE(n < (1ll << 31) - LSD_TILE, "lsd_sort: n=%lld out of range", (long long)n);
     if (end_bit < 1) end_bit = 1;
@@ -273,26 +287,26 @@ static int lsd_sort(Src src, int64_t n, unsigned end_bit, uint32_t* keys_tmp, in
         uint32_t* ko = to_out ? keys_out : keys_tmp;
         int32_t* vo = to_out ? vals_out : vals_tmp;
         if (q == 0) {
-            DR_LAUNCH_NAMED("lsd_hist_kernel", (lsd_hist_kernel<Src>), dim3(ntiles), dim3(LSD_T), 0, st, src, n, shift, mask, hist,
-                            zero3);
+            DR_LAUNCH_NAMED("lsd_hist_kernel", (lsd_hist_kernel<Src>), dim3(ntiles), dim3(LSD_T), 0, st, src, n, n_dev, shift, mask,
+                            hist, zero3);
         } else {
             LsdPairs prev{to_out ? keys_tmp : keys_out, to_out ? vals_tmp : vals_out};
-            DR_LAUNCH_NAMED("lsd_hist_kernel", (lsd_hist_kernel<LsdPairs>), dim3(ntiles), dim3(LSD_T), 0, st, prev, n, shift, mask,
-                            hist, (int32_t*)nullptr);
+            DR_LAUNCH_NAMED("lsd_hist_kernel", (lsd_hist_kernel<LsdPairs>), dim3(ntiles), dim3(LSD_T), 0, st, prev, n, n_dev, shift,
+                            mask, hist, (int32_t*)nullptr);
         }
         DR_CHECK_LAUNCH("lsd_hist_kernel");
         if (colpre) {
             DR_LAUNCH_NAMED("lsd_colscan_kernel", lsd_colscan_kernel, dim3((LSD_BINS + 255) / 256), dim3(256), 0, st,
-                            (const uint16_t*)hist, ntiles, colpre, total);
+                            (const uint16_t*)hist, ntiles, n_dev, colpre, total);
             DR_CHECK_LAUNCH("lsd_colscan_kernel");
         }
         if (q == 0) {
-            DR_LAUNCH_NAMED("lsd_scatter_kernel", (lsd_scatter_kernel<Src>), dim3(ntiles), dim3(LSD_T), 0, st, src, n, shift, mask,
-                            bits, (const uint16_t*)hist, ntiles, (const uint32_t*)colpre, (const uint32_t*)total, ko, vo);
+            DR_LAUNCH_NAMED("lsd_scatter_kernel", (lsd_scatter_kernel<Src>), dim3(ntiles), dim3(LSD_T), 0, st, src, n, n_dev, shift,
+                            mask, bits, (const uint16_t*)hist, ntiles, (const uint32_t*)colpre, (const uint32_t*)total, ko, vo);
         } else {
             LsdPairs prev{to_out ? keys_tmp : keys_out, to_out ? vals_tmp : vals_out};
-            DR_LAUNCH_NAMED("lsd_scatter_kernel", (lsd_scatter_kernel<LsdPairs>), dim3(ntiles), dim3(LSD_T), 0, st, prev, n, shift,
-                            mask, bits, (const uint16_t*)hist, ntiles, (const uint32_t*)colpre, (const uint32_t*)total, ko, vo);
+            DR_LAUNCH_NAMED("lsd_scatter_kernel", (lsd_scatter_kernel<LsdPairs>), dim3(ntiles), dim3(LSD_T), 0, st, prev, n, n_dev,
+                            shift, mask, bits, (const uint16_t*)hist, ntiles, (const uint32_t*)colpre, (const uint32_t*)total, ko, vo);
         }
         DR_CHECK_LAUNCH("lsd_scatter_kernel");
     }

@@ -112,8 +112,9 @@ static int plan_layout_compute(int64_t n, int k_max, PlanLayout* L, char* err) {
     L->msrc = take(nn * 4);
     L->mcoef = take(nn * 4);
     L->solo = take(nn);  // one byte per ORIGINAL position: its segment has exactly one contribution (BPR plans)
-    L->multi = take((nn / 2 + 1) * 16);  // int4 {segment, key, first sorted position, length} of every segment with
-                                         // 2 .. LONG_SEG contributions (arbitrary order), count in hdr[4]
+    L->multi = take((nn + 1) * 16);  // int4 {segment, key, first sorted position, length} of every segment with
+                                     // 2 .. LONG_SEG contributions (sharded step: also a single one that arrives from a
+                                     // peer), arbitrary order, count in hdr[4]
     L->long_cnt = take(max_long * 4);    // blocks of a long segment summed so far (bpr_tail_kernel), zero between uses
     L->lsd = take(lsd_scratch_bytes(nn));  // tile histograms (+ column prefixes) of the plan's LSD sort
     L->partials = take(L->partial_rows * (int64_t)(k_max > 0 ? k_max : 1) * 4);
@@ -280,18 +281,63 @@ __global__ __launch_bounds__(256) void bpr_meta_kernel(const int32_t* __restrict
 // the first item-side segment, is the number of user-side keys).  A workgroup owns 1024 consecutive sorted positions
 // (keys in LDS); a long run that leaves the workgroup's range finds its end by a galloping search in memory.
 constexpr int FIN_TILE = 1024;
+// What differs between the single-GPU step and the row-sharded one (shard.hip) is where a contribution's source row
+// lives and who applies a row with ONE contribution:
+struct FinBpr {   // positions [0, B): user rows (stash row p), [B, 3B): item rows of sample x = (p - B) mod B
+    const int32_t* u;
+    int64_t B, nu, ni;
+    unsigned char* solo;
+    __device__ __forceinline__ int64_t length(int64_t n) const { return n; }
+    __device__ __forceinline__ uint32_t split() const { return (uint32_t)nu; }
+    __device__ __forceinline__ uint32_t sentinel() const { return (uint32_t)(nu + ni); }
+    __device__ __forceinline__ int32_t msrc(int p) const { return bpr_msrc(p, u, B, nu, 1); }
+    __device__ __forceinline__ bool local(int) const { return true; }
+    __device__ __forceinline__ void solo_store(int p, bool single) const { solo[p] = single ? 1 : 0; }
+};
+// Row-sharded step: the list is [u_loc (n_s entries) ; nuL + local item row (n_g entries, canonical order)], lengths on
+// the device.  osrc[p] of an item entry: 2 s + slot >= 0 when this rank processes the sample (the contribution is
+// (+-g) * the pre-step user row in stash row cap_s + s), -1 - y when the gradient row arrives from a peer (row y of the
+// receive buffer, source index 2 cap_s + y).  A single contribution that arrives from a peer is the tail's, not the
+// forward kernel's.
+struct FinShard {
+    const int32_t* n_dev;       // [0] n_s, [1] n_s + n_g
+    const int32_t* osrc;
+    int64_t cap_s, nuL, niL;
+    unsigned char* solo;        // [3][cap_s]: user, item i, item j of local sample s
+    __device__ __forceinline__ int64_t length(int64_t) const { return n_dev[1]; }
+    __device__ __forceinline__ uint32_t split() const { return (uint32_t)nuL; }
+    __device__ __forceinline__ uint32_t sentinel() const { return 0xFFFFFFFEu; }   // the sharded route refuses invalid ids
+    __device__ __forceinline__ int32_t msrc(int p) const {
+        if (p < n_dev[0]) return p;
+        const int o = osrc[p];
+        return o >= 0 ? (int32_t)(cap_s + (o >> 1)) : (int32_t)(2 * cap_s + (-1 - o));
+    }
+    __device__ __forceinline__ bool local(int p) const { return p < n_dev[0] || osrc[p] >= 0; }
+    __device__ __forceinline__ void solo_store(int p, bool single) const {
+        if (p < n_dev[0]) {
+            solo[p] = single ? 1 : 0;
+        } else {
+            const int o = osrc[p];
+            if (o >= 0) solo[(int64_t)(1 + (o & 1)) * cap_s + (o >> 1)] = single ? 1 : 0;
+        }
+    }
+};
+
+template <class Fin>
 __global__ __launch_bounds__(256) void bpr_finish_kernel(const uint32_t* __restrict__ sk, const int32_t* __restrict__ spos,
-                                                         int64_t n, const int32_t* __restrict__ u, int64_t B, int64_t nu,
-                                                         int64_t ni, int32_t* __restrict__ hdr, int32_t* __restrict__ uniq,
+                                                         int64_t n, Fin fin, int32_t* __restrict__ hdr,
+                                                         int32_t* __restrict__ uniq,
                                                          int32_t* __restrict__ seg_start, int32_t* __restrict__ long_seg,
                                                          int32_t* __restrict__ long_cb, int32_t* __restrict__ long_cnt,
                                                          int32_t* __restrict__ part_owner, int4* __restrict__ multi,
-                                                         int32_t* __restrict__ msrc, unsigned char* __restrict__ solo) {
+                                                         int32_t* __restrict__ msrc) {
+    n = fin.length(n);
     __shared__ uint32_t lk[FIN_TILE];
     __shared__ int wcnt[4];
     __shared__ int blk_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * FIN_TILE;
+    if (base >= n) return;   // block-uniform (the launch may be sized for a capacity beyond the list)
     const int64_t end = (base + FIN_TILE < n) ? base + FIN_TILE : n;
     constexpr uint32_t NONE = 0xFFFFFFFFu;  // never a key (keys <= nu + ni < 2^32 - 2)
 #pragma unroll
@@ -304,11 +350,11 @@ __global__ __launch_bounds__(256) void bpr_finish_kernel(const uint32_t* __restr
         if (y >= base && y < base + FIN_TILE) return lk[y - base];
         return (y >= 0 && y < n) ? sk[y] : NONE;
     };
-    const uint32_t sentinel = (uint32_t)(nu + ni), split = (uint32_t)nu;
+    const uint32_t sentinel = fin.sentinel(), split = fin.split();
     // this thread's four consecutive sorted positions
-    int n_multi = 0, m_len[2] = {0, 0};
-    int64_t m_y[2] = {0, 0};
-    uint32_t m_key[2] = {0u, 0u};
+    int n_multi = 0, m_len[4] = {0, 0, 0, 0};
+    int64_t m_y[4] = {0, 0, 0, 0};
+    uint32_t m_key[4] = {0u, 0u, 0u, 0u};
     int64_t l_y = -1, l_end = 0;
     uint32_t l_key = 0u;
     const int64_t y0 = base + (int64_t)tid * 4;
@@ -331,8 +377,16 @@ __global__ __launch_bounds__(256) void bpr_finish_kernel(const uint32_t* __restr
         const uint32_t next = keyat(y + 1);
         const bool head = prev != key, last = next != key;
         const int p = pp[q];
-        solo[p] = (key != sentinel && head && last) ? 1 : 0;
-        (&ms.x)[q] = bpr_msrc(p, u, B, nu, 1);
+        const bool single = key != sentinel && head && last;
+        const bool mine = fin.local(p);   // a single contribution from a peer is the tail's: a one-entry descriptor
+        fin.solo_store(p, single && mine);
+        (&ms.x)[q] = fin.msrc(p);
+        if (single && !mine) {
+            m_y[n_multi] = y;
+            m_key[n_multi] = key;
+            m_len[n_multi] = 1;
+            ++n_multi;
+        }
         // hdr[3] = number of user-side keys = index of the first item-side segment (prev = NONE at y = 0)
         if (key >= split && (prev < split || y == 0)) hdr[3] = (int32_t)y;
         if (y == n - 1 && key < split) hdr[3] = (int32_t)n;
@@ -1091,8 +1145,8 @@ __global__ __launch_bounds__(256) void bpr_tail_combine_kernel(TailArgs t) {
 template <int V, int LPR>
 static void launch_tail(const TailArgs& t, int64_t n, hipStream_t st) {
     constexpr int SPB = 256 / LPR;
-    // work items <= n / DR_SEG_CHUNK + n / LONG_SEG (long blocks) + n / 2 (multi rows)
-    const int64_t items = n / DR_SEG_CHUNK + n / LONG_SEG + n / 2 + 1;
+    // work items <= n / DR_SEG_CHUNK + n / LONG_SEG (long blocks) + n (multi rows; n / 2 in the single-GPU step)
+    const int64_t items = n / DR_SEG_CHUNK + n / LONG_SEG + n + 1;
     const int64_t blocks = (items + SPB - 1) / SPB;
     const int cgrid = grid_for(n / LONG_SEG + 1, 1, SPB) + (t.loss_out ? 1 : 0);
     // Twice the resident blocks: a sub-wave then takes ONE work item (a 32-contribution block sum is 2 - 3 times a
@@ -1362,11 +1416,12 @@ int plan_build_bpr(const int32_t* u, const int32_t* i, const int32_t* j, int64_t
     int rc = plan_finish(LsdBpr{u, i, j, B, nu, ni}, base, L, n, end_bit, (uint32_t)nu, st, !finish);
     if (rc != DR_OK) return rc;
     if (finish) {
-        DR_LAUNCH_NAMED("bpr_finish_kernel", bpr_finish_kernel, dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)), dim3(256), 0,
-                        st, (const uint32_t*)(base + L.keys_out), (const int32_t*)(base + L.vals_out), n, u, B, nu, ni, hdr,
+        FinBpr fin{u, B, nu, ni, (unsigned char*)(base + L.solo)};
+        DR_LAUNCH_NAMED("bpr_finish_kernel", (bpr_finish_kernel<FinBpr>), dim3((unsigned)((n + FIN_TILE - 1) / FIN_TILE)),
+                        dim3(256), 0, st, (const uint32_t*)(base + L.keys_out), (const int32_t*)(base + L.vals_out), n, fin, hdr,
                         (int32_t*)(base + L.uniq), (int32_t*)(base + L.seg_start), (int32_t*)(base + L.long_seg),
                         (int32_t*)(base + L.long_cb), (int32_t*)(base + L.long_cnt), (int32_t*)(base + L.part_owner),
-                        (int4*)(base + L.multi), (int32_t*)(base + L.msrc), (unsigned char*)(base + L.solo));
+                        (int4*)(base + L.multi), (int32_t*)(base + L.msrc));
         DR_CHECK_LAUNCH("bpr_finish_kernel");
         return DR_OK;
     }
@@ -1545,6 +1600,78 @@ int bpr_tail_launch(float* P, float* Ps0, float* Ps1, int64_t nu, float* Q, floa
 #undef DR_T
     DR_REQUIRE(ok, "bpr tail: unsupported k=%d", k);
     DR_CHECK_LAUNCH("bpr_tail_kernel");
+    return DR_OK;
+}
+
+// ---- row-sharded step (shard.hip) ---------------------------------------------------------------------------------
+// Plan over a rank's combined key list ckey [u_loc ; nuL + local item row] whose length lives on the device (n_dev[1];
+// n_dev[0] = number of user entries): LSD sort + bpr_finish_kernel<FinShard>, all launches sized for the capacity cap_k.
+int64_t plan_shard_bytes(int64_t cap_k, int k) {
+    PlanLayout L;
+    if (plan_layout(cap_k, k, &L, last_error_buf()) != 0) return -1;
+    return L.total;
+}
+int plan_build_shard(const uint32_t* ckey, const int32_t* n_dev, const int32_t* osrc, int64_t cap_s, int64_t cap_k,
+                     int64_t nuL, int64_t niL, unsigned char* solo, void* plan, int64_t plan_bytes, int k, hipStream_t st) {
+    DR_REQUIRE(cap_k >= 1 && cap_k < (1ll << 31) - 4096 && nuL + niL < (1ll << 32) - 2 && 2 * cap_s + cap_k < (1ll << 31) - 1,
+               "shard plan: sizes exceed 32-bit keys / positions");
+    PlanLayout L;
+    if (plan_layout(cap_k, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "shard plan: workspace %lld < required %lld", (long long)plan_bytes, (long long)L.total);
+    char* base = (char*)plan;
+    int32_t* hdr = (int32_t*)(base + L.hdr);
+    unsigned end_bit = 1;
+    while (end_bit < 32 && ((uint64_t)(nuL + niL) >> end_bit) != 0) ++end_bit;
+    int rc = lsd_sort(LsdKeysOnly{ckey}, cap_k, end_bit, (uint32_t*)(base + L.keys_in), (int32_t*)(base + L.vals_in),
+                      (uint32_t*)(base + L.keys_out), (int32_t*)(base + L.vals_out), base + L.lsd, hdr, st, n_dev + 1);
+    if (rc != DR_OK) return rc;
+    FinShard fin{n_dev, osrc, cap_s, nuL, niL, solo};
+    DR_LAUNCH_NAMED("bpr_finish_kernel", (bpr_finish_kernel<FinShard>), dim3((unsigned)((cap_k + FIN_TILE - 1) / FIN_TILE)),
+                    dim3(256), 0, st, (const uint32_t*)(base + L.keys_out), (const int32_t*)(base + L.vals_out), cap_k, fin, hdr,
+                    (int32_t*)(base + L.uniq), (int32_t*)(base + L.seg_start), (int32_t*)(base + L.long_seg),
+                    (int32_t*)(base + L.long_cb), (int32_t*)(base + L.long_cnt), (int32_t*)(base + L.part_owner),
+                    (int4*)(base + L.multi), (int32_t*)(base + L.msrc));
+    DR_CHECK_LAUNCH("bpr_finish_kernel<shard>");
+    return DR_OK;
+}
+
+// The sharded step's tail: bpr_tail_kernel over the plan above.  Sources: stash rows [0, cap_s) = g (q_i - q_j) of the
+// local samples (user side), [cap_s, 2 cap_s) = their pre-step user rows (item side, coefficient +-g from `coef`), and
+// the rows received from the peers (source indices from 2 cap_s on, coefficient 1: the sender multiplied already).
+int shard_tail_launch(float* P, float* Ps0, float* Ps1, int64_t nuL, float* Q, float* Qs0, float* Qs1, int64_t niL, int k,
+                      int64_t cap_s, int64_t cap_k, const float* stash, const float* recv, const float* coef, void* plan,
+                      int64_t plan_bytes, const dr_opt_params* opt, hipStream_t st, const float* loss_b, float* loss_out) {
+    PlanLayout L;
+    if (plan_layout(cap_k, k, &L, last_error_buf()) != 0) return DR_ERR_LAUNCH;
+    if (plan_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "shard tail: plan workspace %lld < required %lld", (long long)plan_bytes, (long long)L.total);
+    char* base = (char*)plan;
+    TailArgs t;
+    int rc = seg_fill(t.q, L, base, Q, Qs0, Qs1, niL, k, stash, 2 * cap_s, nullptr, coef, cap_k, plan, opt->kind, opt, st, true,
+                      SegSel{(uint32_t)nuL, 2, 0}, recv, true);
+    if (rc != DR_OK) return rc;
+    rc = seg_fill(t.p, L, base, P, Ps0, Ps1, nuL, k, stash, 2 * cap_s, nullptr, nullptr, cap_k, plan, opt->kind, opt, st, true,
+                  SegSel{0, 1, 0}, nullptr, true);
+    if (rc != DR_OK) return rc;
+    t.multi = (const int4*)(base + L.multi);
+    t.long_cnt = (int32_t*)(base + L.long_cnt);
+    t.loss_b = loss_b;
+    t.loss_out = loss_out;
+    t.loss_n = cap_s;
+    RowShape s = row_shape(k);
+    bool ok = false;
+#define DR_T(V_, L_)                          \
+    if (!ok && s.V == V_ && s.LPR == L_) {    \
+        launch_tail<V_, L_>(t, cap_k, st);    \
+        ok = true;                            \
+    }
+    DR_T(4, 1) DR_T(4, 2) DR_T(4, 4) DR_T(4, 8) DR_T(4, 16) DR_T(4, 32) DR_T(4, 64)
+    DR_T(2, 1) DR_T(2, 2) DR_T(2, 4) DR_T(2, 8) DR_T(2, 16) DR_T(2, 32) DR_T(2, 64)
+    DR_T(1, 1) DR_T(1, 2) DR_T(1, 4) DR_T(1, 8) DR_T(1, 16) DR_T(1, 32) DR_T(1, 64)
+#undef DR_T
+    DR_REQUIRE(ok, "shard tail: unsupported k=%d", k);
+    DR_CHECK_LAUNCH("bpr_tail_kernel<shard>");
     return DR_OK;
 }
 

@@ -220,51 +220,104 @@ def bucket_order(keys, nkeys):
     return order, counts
 
 
-def _route_ws(n_keys, device):
-    need = check(_abi.lib().dr_route_bytes(int(n_keys)), "dr_route_bytes")
-    return torch.empty(max(need, 256), dtype=torch.uint8, device=device)
-
-
-class RouteViews:
-    """Outputs of route_views (device tensors sized for the worst case; `counts` says how much of each is used)."""
-    __slots__ = ("u_loc", "rows", "inv", "order", "perm", "uniq", "counts", "n_list")
-
-
-def route_views(ids, me, num_user, num_item, rows_per_owner):
-    """Both roles of rank `me` in a row-sharded BPR step from the replicated id lists ids [world, 3, B] (int32):
-    dr_route_views_i32 (include/deeprec_amd.h).  Every output except u_loc / counts is [2, 2 world B] (view 0: what this
-    rank processes, view 1: what it owns).  No host synchronisation."""
-    ids = _req(ids, torch.int32, "ids", 3)
-    W, three, B = ids.shape
-    if three != 3:
-        raise ValueError("ids must be [world, 3, B]")
-    dev = ids.device
-    n = 2 * W * B
-    r = RouteViews()
-    r.n_list = n
-    buf = torch.empty((5, 2, max(n, 1)), dtype=torch.int32, device=dev)
-    r.rows, r.inv, r.order, r.perm, r.uniq = buf[0], buf[1], buf[2], buf[3], buf[4]
-    r.u_loc = torch.empty(max(W * B, 1), dtype=torch.int32, device=dev)
-    r.counts = torch.empty(4 * W + 3, dtype=torch.int64, device=dev)
-    ws = _route_ws(2 * n + 1, dev)
-    check(_abi.lib().dr_route_views_i32(_ptr(ids), W, B, int(me), int(num_user), int(num_item), int(rows_per_owner),
-                                        _ptr(r.u_loc), _ptr(r.rows), _ptr(r.inv), _ptr(r.order), _ptr(r.perm),
-                                        _ptr(r.uniq), _ptr(r.counts), _ptr(ws), ws.numel(), _stream()),
-          "dr_route_views_i32")
-    return r
-
-
-def bpr_item_grads(P, u_loc, g, order):
-    """Item-side gradient rows of a BPR batch in wire order: out[y] = (+-g[s]) * P[u_loc[s]], e = order[y], s = e mod n,
-    minus for e >= n (bprmf.py:118-121: d loss / d q_i = g * p_u, d loss / d q_j = -g * p_u)."""
-    P = _req(P, torch.float32, "P", 2)
-    n = _i32(u_loc, "u_loc").numel()
-    if _req(g, torch.float32, "g", 1).numel() != n or _i32(order, "order").numel() != 2 * n:
-        raise ValueError("g must be [n], order [2n]")
-    out = torch.empty((2 * n, P.shape[1]), dtype=torch.float32, device=P.device)
-    check(_abi.lib().dr_bpr_item_grads_f32(_ptr(P), P.shape[0], P.shape[1], _ptr(u_loc), _ptr(g), _ptr(order), n,
-                                           _ptr(out), _stream()), "dr_bpr_item_grads_f32")
+def gather_into(table, ids, out):
+    """gather() into a caller-provided buffer (out [n, k] float32, contiguous): no allocation."""
+    table = _req(table, torch.float32, "table", 2)
+    ids = _i32(ids, "ids")
+    n = ids.numel()
+    if _req(out, torch.float32, "out", 2).shape != (n, table.shape[1]):
+        raise ValueError("out must be [%d, %d]" % (n, table.shape[1]))
+    check(_abi.lib().dr_gather_f32(_ptr(table), table.shape[0], table.shape[1], _ptr(ids), n, 32, _ptr(out), OOB_ZERO,
+                                   None, _stream()), "dr_gather_f32")
     return out
+
+
+# ------------------------------------------------------------------ row-sharded BPR step (csrc/shard.hip)
+def shard_caps(world, B):
+    """Default capacities of a rank: samples it may process / item entries it may own per step.  The mean loads are B
+    and 2 B; Zipf-popular items make the owner of item 0 carry ~1.5 x the mean at world 8."""
+    return min(world * B, max(2 * B, B + 4096)), min(2 * world * B, max(4 * B, 2 * B + 8192))
+
+
+class ShardWorkspace:
+    """Device workspace of ONE routed batch of the row-sharded step (route lists, plan, stash, losses); `counts` and
+    `serve` are views into it (include/deeprec_amd.h: dr_shard_bpr_list)."""
+
+    def __init__(self, world, me, B, k, num_user, num_item, device, cap_s=None, cap_g=None):
+        d_s, d_g = shard_caps(world, B)
+        self.world, self.me, self.B, self.k = int(world), int(me), int(B), int(k)
+        self.num_user, self.num_item = int(num_user), int(num_item)
+        self.cap_s, self.cap_g = int(cap_s or d_s), int(cap_g or d_g)
+        need = check(_abi.lib().dr_shard_bpr_bytes(self.world, self.B, self.k, self.cap_s, self.cap_g), "dr_shard_bpr_bytes")
+        self.buf = torch.empty(need, dtype=torch.uint8, device=device)
+        self.counts = self.list(0)
+        self.serve = self.list(1)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def _sizes(self):
+        return (self.world, self.me, self.B, self.num_user, self.num_item, self.k, self.cap_s, self.cap_g)
+
+    def list(self, which):
+        """View of one list inside the workspace (dr_shard_bpr_list): 0 counts, 1 serve rows, 2 combined keys, 3 entry
+        sources, 4 item row references [2, cap_s], 5 list / wire positions [2, cap_s], 6 solo flags [3, cap_s] (uint8),
+        7 coefficients (float32)."""
+        p = C.c_void_p()
+        check(_abi.lib().dr_shard_bpr_list(self.world, self.B, self.k, self.cap_s, self.cap_g, _ptr(self.buf), int(which),
+                                           C.byref(p)), "dr_shard_bpr_list")
+        off = p.value - self.buf.data_ptr()
+        ck = self.cap_s + self.cap_g
+        if which == 6:
+            return self.buf[off:off + 3 * self.cap_s].view(3, self.cap_s)
+        n = {0: 8 + 6 * self.world, 1: self.cap_g, 2: ck, 3: ck, 4: 2 * self.cap_s, 5: 2 * self.cap_s, 7: ck}[which]
+        v = self.buf[off:off + 4 * n].view(torch.float32 if which == 7 else torch.int32)
+        return v.view(2, self.cap_s) if which in (4, 5) else v
+
+
+def shard_route(ws, ids):
+    """dr_shard_bpr_route: ids = [world, 3, B] int32 (every rank's u, i, j).  No host synchronisation; read ws.counts
+    afterwards for the split sizes of the two row exchanges."""
+    ids = _req(ids, torch.int32, "ids", 3)
+    if tuple(ids.shape) != (ws.world, 3, ws.B):
+        raise ValueError("ids must be [%d, 3, %d]" % (ws.world, ws.B))
+    check(_abi.lib().dr_shard_bpr_route(_ptr(ids), ws.world, ws.me, ws.B, ws.num_user, ws.num_item, ws.k, ws.cap_s,
+                                        ws.cap_g, _ptr(ws.buf), ws.buf.numel(), _stream()), "dr_shard_bpr_route")
+
+
+def _shard_tables(ws, P, Q, slotsP, slotsQ, opt, who):
+    P = _req(P, torch.float32, "P", 2)
+    Q = _req(Q, torch.float32, "Q", 2)
+    nuL = (ws.num_user - ws.me + ws.world - 1) // ws.world
+    niL = (ws.num_item - ws.me + ws.world - 1) // ws.world
+    if tuple(P.shape) != (nuL, ws.k) or tuple(Q.shape) != (niL, ws.k):
+        raise ValueError("%s: P / Q must be this rank's shards [%d, %d] / [%d, %d]" % (who, nuL, ws.k, niL, ws.k))
+    _slots(opt, slotsP[0], slotsP[1], P, who + "(P)")
+    _slots(opt, slotsQ[0], slotsQ[1], Q, who + "(Q)")
+
+
+def shard_forward(ws, P, Q, slotsP, slotsQ, opt, fetched=None, send=None):
+    """dr_shard_bpr_forward on the batch routed into ws.  fetched [>= rows fetched, k] / send [>= rows sent, k]: the
+    exchange buffers (None at world 1)."""
+    _shard_tables(ws, P, Q, slotsP, slotsQ, opt, "shard_forward")
+    for name, t in (("fetched", fetched), ("send", send)):
+        if t is not None and _req(t, torch.float32, name, 2).shape[1] != ws.k:
+            raise ValueError("%s must have %d columns" % (name, ws.k))
+    if ws.world > 1 and (fetched is None or send is None or send.shape[0] < 2 * ws.cap_s or fetched.shape[0] < 2 * ws.cap_s):
+        raise ValueError("shard_forward: fetched / send need 2 * cap_s = %d rows" % (2 * ws.cap_s))
+    check(_abi.lib().dr_shard_bpr_forward(_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), _ptr(Q), _ptr(slotsQ[0]),
+                                          _ptr(slotsQ[1]), *ws._sizes(), _ptr(fetched), _ptr(send), C.byref(opt),
+                                          _ptr(ws.buf), ws.buf.numel(), _stream()), "dr_shard_bpr_forward")
+
+
+def shard_finish(ws, P, Q, slotsP, slotsQ, opt, received=None):
+    """dr_shard_bpr_finish; returns the device scalar loss sum of the samples this rank processed."""
+    _shard_tables(ws, P, Q, slotsP, slotsQ, opt, "shard_finish")
+    if ws.world > 1 and (received is None or _req(received, torch.float32, "received", 2).shape[1] != ws.k
+                         or received.shape[0] < ws.cap_g):
+        raise ValueError("shard_finish: received needs cap_g = %d rows of %d columns" % (ws.cap_g, ws.k))
+    check(_abi.lib().dr_shard_bpr_finish(_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), _ptr(Q), _ptr(slotsQ[0]),
+                                         _ptr(slotsQ[1]), *ws._sizes(), _ptr(received), C.byref(opt), _ptr(ws.loss),
+                                         _ptr(ws.buf), ws.buf.numel(), _stream()), "dr_shard_bpr_finish")
+    return ws.loss
 
 
 def scatter_add(gtable, ids, src, src_idx=None, coef=None, plan=None):

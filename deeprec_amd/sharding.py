@@ -5,26 +5,31 @@ One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  A ta
 dealt round-robin: global row r lives on rank r % W at local row r // W (balances popular items
 better than contiguous blocks).
 
-A BPR step moves the *sample* to the data where that is cheaper than moving the data to the sample:
+A BPR step (bprmf.py:114-123) moves the *sample* to the data where that is cheaper than moving the data to the sample:
 
     id lists (u, i, j)           -> every rank             12 B per sample, ONE fixed-size all-gather
-    distinct item rows           <- the owners of Q rows   4k B per DISTINCT item a rank's samples touch
-    item gradient rows           -> the owners of Q rows   4k B per (sample, item) contribution
+    distinct item rows           <- the owners of Q rows   4k B per DISTINCT remote item a rank's samples touch
+    item gradient rows           -> the owners of Q rows   4k B per (sample, remote item) contribution
 
 User rows never travel: a sample is processed by the rank that owns P[u].  Because the ids are replicated, every
-rank derives BOTH of its roles locally (`dr_route_views_i32`: what it processes and what it owns) -- which rows each
+rank derives BOTH of its roles locally (dr_shard_bpr_route: what it processes and what it owns) -- which rows each
 peer will request from it, in which order the gradient rows of each peer arrive, and where each of them stands in
 the canonical order -- so no requests, counts or metadata are exchanged and a route needs one collective and one
 host synchronisation (the variable split sizes of the two row exchanges).
 
-The processing rank runs the lookup / dot / loss kernel on its own P shard and the fetched Q rows, updates its P
-rows locally, and ships one gradient row per item occurrence.  Duplicate item gradients are NOT pre-summed on the
-sender: the owner sums them in the order a single process sees for the concatenated global batch (i-part before
-j-part, then source rank, then batch position), so the tables are bit-identical at every world size.
+Round 3: the processing rank runs the FUSED step (csrc/shard.hip).  Its combined key list [user rows of its samples ;
+item rows it owns, in canonical order] is planned exactly like the single-GPU step's -- at W = 1 it IS that list and
+the step is the fused step: no exchange, no copy.  Rows with one local contribution are updated by the forward
+kernel; item rows of its samples that live elsewhere are read from the fetch buffer and their gradient rows are
+written straight into the send buffer; one tail pass applies every other row of both tables, taking contributions
+that arrived from peers from the receive buffer.  Duplicate item gradients are NOT pre-summed on the sender: the
+owner sums them in the order a single process sees for the concatenated global batch (i-part before j-part, then
+source rank, then batch position), so the tables are bit-identical at every world size.
 
 Everything that depends on the ids only (`route`) is separated from what depends on table values (`run`), so a
 trainer routes batch t+1 on a second stream / second communicator while batch t runs
 (`ShardedBpr.step(..., next_batch=...)`); the host synchronisation of a route then waits on short id kernels only.
+Every per-step buffer (three route workspaces, id lists, exchange buffers, pinned split sizes) is allocated once.
 
 `ops` is the kernel namespace (default: deeprec_amd.kernels = the HIP library).  The package ships no
 other implementation; tests inject an oracle-backed namespace to exercise the exchange logic on CPU
@@ -86,23 +91,27 @@ def _side_stream(device):
 
 
 class BprRoute:
-    """Everything about one step that depends on the ids only (see ShardedBpr.route)."""
-    __slots__ = ("n_s", "n_uq", "n_f", "n_g", "send_f", "recv_f", "send_g", "recv_g", "u_loc", "inv_i", "inv_j",
-                 "order_g", "rows_fetch", "ids_canon", "perm", "plan_p", "plan_q", "ready", "keep")
+    """One routed batch: its workspace slot and, after finish(), the split sizes of the two row exchanges."""
+    __slots__ = ("slot", "ws", "n_fetch", "n_serve", "n_send", "n_recv", "send_f", "recv_f", "send_g", "recv_g", "ready",
+                 "counted")
 
 
 class ShardedBpr:
     """BPR-MF training steps (bprmf.py:114-123) over row-sharded P and Q.
 
-    route(u, i, j) -> BprRoute      ids only: 1 collective (id all-gather), 1 host sync, the owners' segment plans
+    route(u, i, j) -> BprRoute      ids only: 1 collective (id all-gather), 1 host sync, the rank's plan
     run(route, opt) -> loss         table values: 2 collectives (rows in, gradient rows out), no host sync
     step(opt, next_batch)           run the prefetched route, then route next_batch on the side stream
 
-    Every rank passes a batch of the SAME length (the all-gather is fixed-size).
+    Every rank passes a batch of the SAME length (the all-gather is fixed-size), the same on every call.
     group: communicator of the row / gradient exchanges; route_group: communicator of the id all-gather (created
-    here when the step is pipelined on GPUs, because the two run concurrently on different streams)."""
+    here when the step is pipelined on GPUs, because the two run concurrently on different streams).
+    caps = (cap_s, cap_g): the most samples a rank may process / item entries it may own per step (default
+    ops.shard_caps); a batch beyond them is refused by every rank together."""
 
-    def __init__(self, ops, P, Q, group=None, route_group=None, pipelined=None):
+    SLOTS = 3       # route workspaces: the batch that runs + two routed ahead
+
+    def __init__(self, ops, P, Q, group=None, route_group=None, pipelined=None, caps=None):
         if P.world != Q.world or P.rank != Q.rank or P.k != Q.k:
             raise ValueError("P and Q must be sharded over the same ranks and share k")
         self.ops, self.P, self.Q = ops, P, Q
@@ -112,109 +121,116 @@ class ShardedBpr:
         self.cuda = P.w.is_cuda
         self.pipelined = self.cuda if pipelined is None else bool(pipelined)
         self.collective = self.world > 1 or (dist.is_available() and dist.is_initialized())
-        if route_group is None and self.pipelined and self.cuda and self.collective:
+        if route_group is None and self.pipelined and self.cuda and self.collective and self.world > 1:
             route_group = dist.new_group()          # collective call: every rank constructs its trainer
         self.route_group = route_group if route_group is not None else group
-        self.rpo = (Q.rows + self.world - 1) // self.world     # local rows per owner (upper bound)
         self.side = _side_stream(P.w.device) if (self.cuda and self.pipelined) else None
-        self._pending = None
-        self._retired = None
+        self.caps = caps
+        self.B = None
+        self._pending = []          # routed batches, oldest first (at most SLOTS - 1)
+        self._next_slot = 0
 
-    # ---- exchanges -------------------------------------------------------------------------------------
-    def _x(self, send, n_out, out_splits, in_splits, group, async_op=False):
-        """All-to-all-v along dim 0.  async_op: returns (out, work); the caller waits before it reads `out`."""
-        if not self.collective:
-            return (send, None) if async_op else send              # one rank, no process group: nothing travels
-        out = torch.empty((n_out,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        work = _a2a(out, send, out_splits, in_splits, group, async_op)
-        return (out, work) if async_op else out
+    # ---- buffers, once -----------------------------------------------------------------------------------
+    def _allocate(self, B):
+        ops, P, Q, W = self.ops, self.P, self.Q, self.world
+        dev = P.w.device
+        cs, cg = self.caps if self.caps is not None else ops.shard_caps(W, B)
+        self.B = B
+        self.ws = [ops.ShardWorkspace(W, self.rank, B, P.k, P.rows, Q.rows, dev, cs, cg) for _ in range(self.SLOTS)]
+        self.ids = [torch.empty((W, 3, B), dtype=torch.int32, device=dev) for _ in range(self.SLOTS)]
+        self.mine = [torch.empty((3, B), dtype=torch.int32, device=dev) for _ in range(self.SLOTS)] if W > 1 else None
+        nc = 8 + 6 * W
+        self.counts_host = [torch.empty(nc, dtype=torch.int32, pin_memory=self.cuda) for _ in range(self.SLOTS)]
+        self.counted = [torch.cuda.Event() for _ in range(self.SLOTS)] if self.cuda else None
+        if W > 1:
+            f32 = dict(dtype=torch.float32, device=dev)
+            self.serve_buf = torch.empty((cg, P.k), **f32)        # rows the peers fetch from this rank
+            self.fetch_buf = torch.empty((2 * cs, P.k), **f32)    # rows this rank fetches
+            self.send_buf = torch.empty((2 * cs, P.k), **f32)     # gradient rows out
+            self.recv_buf = torch.empty((cg, P.k), **f32)         # gradient rows in
 
     # ---- ids only --------------------------------------------------------------------------------------
     def route(self, u, i, j):
         return self._route_finish(self._route_begin(u, i, j))
 
     def _route_begin(self, u, i, j):
-        """The part of a route that needs no host synchronisation: the id all-gather and dr_route_views_i32."""
+        """The part of a route that needs no host synchronisation: the id all-gather, dr_shard_bpr_route and the
+        asynchronous copy of its counts to pinned host memory."""
         ops, W = self.ops, self.world
-        P, Q = self.P, self.Q
         B = u.numel()
-        if i.numel() != B or j.numel() != B:
-            raise ValueError("u, i, j must have the same length")
-        if 4 * W * B >= (1 << 31) - 2:
-            raise ValueError("batch of %d samples per rank on %d ranks exceeds the 31-bit list index" % (B, W))
-        mine = torch.stack((u.reshape(-1), i.reshape(-1), j.reshape(-1))).to(torch.int32)
-        if self.collective:
-            ids = torch.empty((W, 3, B), dtype=torch.int32, device=mine.device)
+        if i.numel() != B or j.numel() != B or B < 1:
+            raise ValueError("u, i, j must have the same (non-zero) length")
+        if self.B is None:
+            if 4 * W * B >= (1 << 31) - 8192:
+                raise ValueError("batch of %d samples per rank on %d ranks exceeds the 31-bit list index" % (B, W))
+            self._allocate(B)
+        if B != self.B:
+            raise ValueError("ShardedBpr was sized for batches of %d samples per rank, got %d" % (self.B, B))
+        rt = BprRoute()
+        rt.slot = self._next_slot
+        self._next_slot = (self._next_slot + 1) % self.SLOTS
+        rt.ws = self.ws[rt.slot]
+        ids = self.ids[rt.slot]
+        if W > 1:
+            mine = self.mine[rt.slot]
+            torch.stack((u.reshape(-1), i.reshape(-1), j.reshape(-1)), out=mine)
             _gather_ids(ids, mine, self.route_group)               # the one collective of a route
         else:
-            ids = mine.reshape(1, 3, B)
-        return ids, ops.route_views(ids, self.rank, P.rows, Q.rows, self.rpo)
-
-    def _route_finish(self, begun):
-        """The host synchronisation of a route (split sizes) and the owners' segment plans."""
-        ops, W = self.ops, self.world
-        P, Q = self.P, self.Q
-        ids, rv = begun
-        c = rv.counts.tolist()                                     # the one host synchronisation of a route
-        # the ids are replicated, so every rank sees the same count: a bad batch on ONE rank is refused by ALL ranks
-        # here, before any of them enters a row exchange
-        if c[4 * W + 2]:
-            raise IndexError("sharded BPR step: %d samples of the global batch have a user / item id out of range"
-                             % c[4 * W + 2])
-        rt = BprRoute()
-        rt.send_f, rt.send_g = c[0:2 * W:2], c[1:2 * W:2]          # view 0, per owner: distinct rows, contributions
-        rt.recv_f, rt.recv_g = c[2 * W:4 * W:2], c[2 * W + 1:4 * W:2]    # view 1, per processing rank
-        n0, n1 = c[4 * W], c[4 * W + 1]
-        rt.n_s, rt.n_g = n0 // 2, n1
-        rt.n_uq, rt.n_f = sum(rt.send_f), sum(rt.recv_f)
-        n_s = rt.n_s
-        rt.u_loc = rv.u_loc[:n_s]
-        rt.inv_i, rt.inv_j = rv.inv[0, :n_s], rv.inv[0, n_s:2 * n_s]
-        rt.order_g = rv.order[0, :2 * n_s]
-        rt.rows_fetch = rv.uniq[1, :rt.n_f]
-        rt.ids_canon, rt.perm = rv.rows[1, :n1], rv.perm[1, :n1]
-        # the owners' segment plans (namespaces without SegmentPlan -- the CPU oracle in tests -- plan in the update)
-        rt.plan_p = rt.plan_q = None
-        if hasattr(ops, "SegmentPlan"):
-            if n_s:
-                rt.plan_p = ops.SegmentPlan(rt.u_loc, P.w.shape[0], k_max=P.k)
-            if rt.n_g:
-                rt.plan_q = ops.SegmentPlan(rt.ids_canon, Q.w.shape[0], k_max=Q.k)
+            torch.stack((u.reshape(-1), i.reshape(-1), j.reshape(-1)), out=ids[0])
+        ops.shard_route(rt.ws, ids)
+        self.counts_host[rt.slot].copy_(rt.ws.counts, non_blocking=True)
+        rt.counted = None
+        if self.cuda:
+            rt.counted = self.counted[rt.slot]
+            rt.counted.record()
         rt.ready = None
-        rt.keep = (ids, rv)                     # alive until the step that uses the route is enqueued
+        return rt
+
+    def _route_finish(self, rt):
+        """The host synchronisation of a route: its counts (split sizes of the two row exchanges, refused batches)."""
+        W = self.world
+        if rt.counted is not None:
+            rt.counted.synchronize()                               # the one host synchronisation of a route
+        c = self.counts_host[rt.slot].tolist()
+        # the ids are replicated, so every rank sees the same numbers: a bad batch on ONE rank is refused by ALL ranks
+        # here, before any of them enters a row exchange
+        if c[4]:
+            raise IndexError("sharded BPR step: %d samples of the global batch have a user / item id out of range" % c[4])
+        if c[5]:
+            raise RuntimeError("sharded BPR step: a rank would process more than %d samples or own more than %d item "
+                               "entries of this batch (per-rank loads: %s samples, %s entries); pass larger caps"
+                               % (rt.ws.cap_s, rt.ws.cap_g, c[8 + 4 * W:8 + 5 * W], c[8 + 5 * W:8 + 6 * W]))
+        rt.send_f, rt.send_g = c[8:8 + W], c[8 + W:8 + 2 * W]      # per owner: distinct rows to fetch, gradient rows out
+        rt.recv_f, rt.recv_g = c[8 + 2 * W:8 + 3 * W], c[8 + 3 * W:8 + 4 * W]   # per processing rank
+        rt.n_fetch, rt.n_send = sum(rt.send_f), sum(rt.send_g)
+        rt.n_serve, rt.n_recv = sum(rt.recv_f), sum(rt.recv_g)
         return rt
 
     # ---- table values ----------------------------------------------------------------------------------
     def run(self, rt, opt):
         ops, P, Q, g = self.ops, self.P, self.Q, self.group
-        dev = P.w.device
-        # distinct item rows <- owners (the owners run K1 on their shard)
-        served = ops.gather(Q.w, rt.rows_fetch) if rt.n_f else torch.empty((0, Q.k), dtype=torch.float32, device=dev)
-        qc = self._x(served, rt.n_uq, rt.send_f, rt.recv_f, g)
-        if rt.n_s:
-            # lookup + dots + loss on the local P shard and the fetched rows; stash = g * (q_i - q_j)
-            gc, loss_b, stash = ops.bpr_forward(P.w, qc, rt.u_loc, rt.inv_i, rt.inv_j)
-            q_send = ops.bpr_item_grads(P.w, rt.u_loc, gc, rt.order_g)         # reads pre-step P rows
-        else:
-            q_send = torch.empty((0, Q.k), dtype=torch.float32, device=dev)
-        q_grad, travelling = self._x(q_send, rt.n_g, rt.recv_g, rt.send_g, g, async_op=True)
-        # deterministic segment updates; contributions in ascending global batch position.  The user side is local
-        # and runs while the item gradients travel (q_send was computed from the pre-step P rows above).
-        if rt.n_s:
-            ops.sparse_row_update(P.w, P.slot(0), P.slot(1), rt.u_loc, stash, opt, plan=rt.plan_p)
-        if travelling is not None:
-            travelling.wait()
-        if rt.n_g:
-            ops.sparse_row_update(Q.w, Q.slot(0), Q.slot(1), rt.ids_canon, q_grad, opt, src_idx=rt.perm, plan=rt.plan_q)
-        if rt.n_s:
-            return ops.sum_f32(loss_b)
-        return torch.zeros(1, dtype=torch.float32, device=dev)
+        ws = rt.ws
+        sP, sQ = (P.slot(0), P.slot(1)), (Q.slot(0), Q.slot(1))
+        if self.world == 1:
+            # the fused single-GPU step: nothing to fetch, nothing to send
+            ops.shard_forward(ws, P.w, Q.w, sP, sQ, opt)
+            return ops.shard_finish(ws, P.w, Q.w, sP, sQ, opt)
+        # distinct remote item rows <- owners (the owners run K1 on their shard, before any of this step's updates)
+        served = self.serve_buf[:rt.n_serve]
+        ops.gather_into(Q.w, ws.serve[:rt.n_serve], served)
+        _a2a(self.fetch_buf[:rt.n_fetch], served, rt.send_f, rt.recv_f, g)
+        # lookups, dots, loss; rows with one local contribution updated in place; gradient rows of remote items -> send_buf
+        ops.shard_forward(ws, P.w, Q.w, sP, sQ, opt, self.fetch_buf, self.send_buf)
+        _a2a(self.recv_buf[:rt.n_recv], self.send_buf[:rt.n_send], rt.recv_g, rt.send_g, g)
+        # every other row of both tables; contributions in ascending global batch position, local or received
+        return ops.shard_finish(ws, P.w, Q.w, sP, sQ, opt, self.recv_buf)
 
     # ---- one batch ahead -------------------------------------------------------------------------------
     def _begin_ahead(self, u, i, j):
         """Enqueue the sync-free part of a route (on the side stream when pipelined).  The side stream first waits for
         an event recorded HERE on the caller's current stream, so ids produced by earlier work on that stream are
-        complete before the route reads them -- and nothing enqueued on it later delays the route."""
+        complete before the route reads them (and the workspace slot it reuses has been read by the step before the
+        one running now) -- and nothing enqueued on the caller's stream later delays the route."""
         if self.side is None:
             return self._route_begin(u, i, j)
         ready = torch.cuda.Event()
@@ -223,42 +239,32 @@ class ShardedBpr:
         for t in (u, i, j):
             t.record_stream(self.side)              # the caller may drop the batch right after step()
         with torch.cuda.stream(self.side):
-            return self._route_begin(u, i, j)
-
-    def _finish_ahead(self, begun):
-        if self.side is None:
-            return self._route_finish(begun)
-        with torch.cuda.stream(self.side):
-            rt = self._route_finish(begun)
+            rt = self._route_begin(u, i, j)
             rt.ready = torch.cuda.Event()
             rt.ready.record(self.side)
         return rt
 
     def prefetch(self, u, i, j):
-        """Route a batch now (on the side stream when pipelined); step() consumes it."""
-        self._pending = self._finish_ahead(self._begin_ahead(u, i, j))
+        """Route a batch now (on the side stream when pipelined); step() consumes the routed batches in order.  Up to
+        SLOTS - 1 batches may be routed ahead."""
+        if len(self._pending) >= self.SLOTS - 1:
+            raise RuntimeError("ShardedBpr.prefetch: %d batches are routed ahead already" % len(self._pending))
+        self._pending.append(self._begin_ahead(u, i, j))
 
     def step(self, opt, next_batch=None):
-        """Run the prefetched batch; `next_batch` = (u, i, j) is routed meanwhile.  Order on the host: (1) the sync-free
-        part of next_batch's route goes to the side stream, where it waits only for what the caller's stream held at
-        that moment (the previous step); (2) this batch's kernels and exchanges are enqueued; (3) only then the host
-        waits for the route's split sizes -- the id kernels have run beside (2) -- and enqueues the owners' plans.
-        With (3) before (2), as in the first version, the GPU's main stream sat idle through every route's host wait."""
-        rt = self._pending
-        if rt is None:
+        """Run the oldest routed batch; `next_batch` = (u, i, j) is routed meanwhile (behind the ones already waiting).
+        Order on the host: (1) the host reads the counts of the batch to run -- routed one or two steps ago, so its id
+        kernels have long finished; (2) the sync-free route of next_batch goes to the side stream, where it waits only
+        for what the caller's stream held at that moment (the previous step: the last reader of the workspace slot it
+        takes); (3) this batch's kernels and exchanges are enqueued."""
+        if not self._pending:
             raise RuntimeError("ShardedBpr.step: no routed batch (call prefetch first)")
-        self._pending = None
-        begun = self._begin_ahead(*next_batch) if next_batch is not None else None
+        rt = self._route_finish(self._pending.pop(0))
+        if next_batch is not None:
+            self._pending.append(self._begin_ahead(*next_batch))
         if rt.ready is not None:
             rt.ready.wait()                         # the caller's current stream waits for the route's side-stream work
-        loss = self.run(rt, opt)
-        if begun is not None:
-            self._pending = self._finish_ahead(begun)
-        # side-stream memory of this route may be reused only by a route whose kernels wait for this run(): the next
-        # route to be enqueued does (its event is recorded after this point), the one enqueued above does not -- so
-        # the route stays referenced until the step after this one
-        self._retired = rt
-        return loss
+        return self.run(rt, opt)
 
 
 def sharded_bpr_step(ops, P, Q, u, i, j, opt, group=None):

@@ -448,33 +448,47 @@ int32_t dr_seq_dot_loss_f32(const float* W, const float* bias, int64_t num_item,
                             const int32_t* tgt, const int32_t* neg, int64_t B, int32_t T, int32_t Tn,
                             float scale, float* loss_b, float* gW, float* gb, float* gx, void* stream);
 
-/* ---- row-sharded BPR step: routing helpers (no counterpart in the reference; SURVEY 8e, deeprec_amd/sharding.py) ----
- * A sample (u, i, j) is processed by the rank that owns P[u] (u % world); that rank fetches the distinct Q rows its
- * samples need from their owners (row % world) and sends the item-side gradient rows back.  The id lists of all ranks
- * are REPLICATED (one fixed-size all-gather), so each rank derives both of its roles locally and no requests, counts or
- * metadata travel.  ws: dr_route_bytes(number of sorted keys), 256-byte aligned.
+/* ---- row-sharded BPR step (no counterpart in the reference, which is single-device; the step is bprmf.py:114-123;
+ * SURVEY 8e, deeprec_amd/sharding.py, csrc/shard.hip) ----
+ * Tables are dealt round-robin (owner = row % world, local row = row / world); the id lists of all ranks are REPLICATED
+ * (one fixed-size all-gather: ids = [world][3][B] int32, rank s's u, i, j; global sample g = s * B + position).  A rank
+ * PROCESSES the samples whose user row it owns and OWNS the item entries (part i / j, sample) with item % world == me,
+ * in the canonical order a single process sees for the concatenated batch (i-part before j-part, then g).  Its combined
+ * key list [local user rows of its samples ; local item rows it owns] is planned like the single-GPU step's (and is
+ * that list at world 1); item rows of its samples that live elsewhere are fetched (distinct rows per owner, ascending:
+ * first all-to-all-v), their gradient rows (+-g) p_u leave in the same (owner, row, canonical) order (second
+ * all-to-all-v) and are added by the owner with coefficient 1 at their canonical place.  Tables are bit-identical at
+ * every world size.  num_user / num_item: GLOBAL table sizes; P / Q and their slots: this rank's shards.
+ * cap_s / cap_g: the most samples a rank may process / item entries it may own; every rank sees every rank's load
+ * (counts) and refuses a batch beyond them.  k must be V * 2^n (one vector column per lane: 4, 8, ..., 256, or 2 / 1).
+ * ws: dr_shard_bpr_bytes(...), 256-byte aligned; it holds the route, the plan, the stash and the per-sample losses of ONE
+ * batch (route a batch ahead into a second workspace).  Nothing is allocated and no host synchronisation happens inside.
  *
- * dr_route_views_i32: ids = [world][3][B] int32, rank s's (u, i, j) lists; global sample g = s * B + position; list
- * entry e in [0, 2 world B): part = e / (world B) (0: item i, 1: item j) of sample e % (world B) -- ascending e is the
- * order a single process sees for the concatenated global batch (the canonical contribution order).
- *   view 0 (this rank processes): entries of samples with u % world == me, sorted by (owner of the item, local row, e)
- *   view 1 (this rank owns):      entries with item % world == me,         sorted by (u % world,         local row, e)
- * Per view v, written at offset v * 2 world B of every output: c = index of the entry among the view's entries in
- * ascending e, y = its position in the sorted order, s = index of its distinct (major, row):
- *   rows[c] = local row at the owner, inv[c] = s, order[y] = c, perm[c] = y, uniq[s] = row;
- *   u_loc[c] = u / world for the view-0 entries of part 0 (c < samples processed here).
- * counts (int64 [4 world + 3]): [2 (v world + m)] distinct rows, [.. + 1] entries of major m (view 0: owner rank, view 1:
- * processing rank); [4 world + v] entries of view v; [4 world + 2] samples of the GLOBAL batch with an id out of range
- * (they belong to no view; every rank computes the same number and refuses the batch).  Sorted keys: 4 world B + 1.
- * Sender and receiver of every exchange derive the same order: view 0 of rank r restricted to owner o lists the same
- * (row, e) sequence as view 1 of rank o restricted to processing rank r.
- * dr_bpr_item_grads_f32: out[y] = c * P[u_loc[s]] with e = order[y], s = e mod n, c = +g[s] (e < n) or -g[s]. */
-int64_t dr_route_bytes(int64_t n_keys);
-int32_t dr_route_views_i32(const int32_t* ids, int32_t world, int64_t B, int32_t me, int64_t num_user, int64_t num_item,
-                           int64_t rows_per_owner, int32_t* u_loc, int32_t* rows, int32_t* inv, int32_t* order,
-                           int32_t* perm, int32_t* uniq, int64_t* counts, void* ws, int64_t ws_bytes, void* stream);
-int32_t dr_bpr_item_grads_f32(const float* P, int64_t rows, int32_t k, const int32_t* u_loc, const float* g,
-                              const int32_t* order, int64_t n, float* out, void* stream);
+ * dr_shard_bpr_route    ids only: 2 launches + (world > 1: sort of the remote entries + 2) + the plan (7).
+ * dr_shard_bpr_list     device address of a list inside ws.  which = 0: counts (int32 [8 + 6 world]: [0] samples processed here, [1] entries
+ *                       of the combined list, [2] gradient rows sent, [3] sent + received, [4] samples of the GLOBAL batch
+ *                       with an id out of range, [5] some rank over a capacity, [6] item entries owned, [7] gradient rows
+ *                       received; then per rank r: distinct rows fetched from r | gradient rows sent to r | rows r
+ *                       fetches from me | gradient rows r sends me | samples r processes | entries r owns); 1: the local
+ *                       rows the peers fetch from this rank (int32 [cap_g], peer-major, ascending); 2 - 7 (tests): combined
+ *                       key list, entry sources, item row references, list / wire positions, solo flags, coefficients.
+ * dr_shard_bpr_forward  lookups, dots, loss; rows with ONE contribution, and that one local, updated in place; gradient
+ *                       rows of remote items -> send (counts[2] rows); fetched: rows received for counts' first list.
+ * dr_shard_bpr_finish   every other row of both tables (received: counts[7] rows, peer-major) + the loss sum of the
+ *                       samples processed here. */
+int64_t dr_shard_bpr_bytes(int32_t world, int64_t B, int32_t k, int64_t cap_s, int64_t cap_g);
+int32_t dr_shard_bpr_list(int32_t world, int64_t B, int32_t k, int64_t cap_s, int64_t cap_g, void* ws, int32_t which,
+                          void** ptr);
+int32_t dr_shard_bpr_route(const int32_t* ids, int32_t world, int32_t me, int64_t B, int64_t num_user, int64_t num_item,
+                           int32_t k, int64_t cap_s, int64_t cap_g, void* ws, int64_t ws_bytes, void* stream);
+int32_t dr_shard_bpr_forward(float* P, float* Pslot0, float* Pslot1, float* Q, float* Qslot0, float* Qslot1,
+                             int32_t world, int32_t me, int64_t B, int64_t num_user, int64_t num_item, int32_t k,
+                             int64_t cap_s, int64_t cap_g, const float* fetched, float* send, const dr_opt_params* opt,
+                             void* ws, int64_t ws_bytes, void* stream);
+int32_t dr_shard_bpr_finish(float* P, float* Pslot0, float* Pslot1, float* Q, float* Qslot0, float* Qslot1,
+                            int32_t world, int32_t me, int64_t B, int64_t num_user, int64_t num_item, int32_t k,
+                            int64_t cap_s, int64_t cap_g, const float* received, const dr_opt_params* opt, float* loss_out,
+                            void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- measurement hooks (no counterpart in the reference) ---------------------------------------------
  * dr_profile_enable(1): from now on every instrumented kernel launch of this library (the gather kernel, the fused step's forward

@@ -1,7 +1,7 @@
 """GPU tests of the row-sharded BPR step (deeprec_amd/sharding.py) on the real HIP kernels:
 
-* the routing entry points (dr_route_views_i32, dr_bpr_item_grads_f32) against their numpy restatements in
-  tests/_oracle_ops.py, bit for bit;
+* the routing entry point (dr_shard_bpr_route) against its numpy restatement in tests/_oracle_ops.py, list by list
+  and bit for bit;
 * one rank through RCCL (process group of size 1, pipelined trainer with its second communicator and stream);
 * two ranks sharing the one GPU of the box (gloo, device tensors staged through the host for the exchanges --
   RCCL refuses two ranks on one device), pipelined: tables bit-identical to the fused single-GPU step on the
@@ -39,64 +39,106 @@ def _free_port():
 
 
 # ------------------------------------------------------------------ routing kernels vs numpy restatement
-@pytest.mark.parametrize("B,W,ni", [(1, 1, 10), (1000, 1, 701), (4096, 2, 700), (20001, 8, 100000), (5000, 3, 17),
-                                    (300, 5, 3)])
-def test_route_views(dev, B, W, ni):
-    """dr_route_views_i32 for every rank of the world against the numpy restatement, bit for bit; and the property the
-    exchanges rest on: what rank r's processing view sends to owner o is, entry for entry, what o's owner view expects
-    from r."""
+@pytest.mark.parametrize("B,W,ni,k", [(1, 1, 10, 8), (1000, 1, 701, 64), (4096, 2, 700, 64), (20001, 8, 100000, 128),
+                                      (5000, 3, 17, 32), (300, 5, 3, 4), (70000, 4, 1000003, 16)])
+def test_shard_route(dev, B, W, ni, k):
+    """dr_shard_bpr_route for every rank of the world against the numpy restatement (tests/_oracle_ops.py), list by
+    list and bit for bit; and the property the exchanges rest on: the rows rank r fetches from owner o are, entry for
+    entry, the rows o serves to r, and every gradient row r sends to o has a place in o's receive order."""
     from deeprec_amd import kernels as K
     import _oracle_ops as O
     rng = np.random.default_rng(B + W)
     nu = 100003
-    rpo = (ni + W - 1) // W
     ids = np.stack((rng.integers(0, nu, (W, B)), rng.zipf(1.2, (W, B)) % ni, rng.integers(0, ni, (W, B))), 1).astype(np.int32)
-    if B > 10:
-        ids[0, 0, 3], ids[W - 1, 1, 5], ids[0, 2, 7] = -1, ni, -5      # invalid samples belong to no view, counted apart
     views = []
     for me in range(W):
-        got = K.route_views(T(ids, dev), me, nu, ni, rpo)
-        want = O.route_views(torch.from_numpy(ids), me, nu, ni, rpo)
-        c = want.counts.numpy()
-        assert np.array_equal(N(got.counts), c), me
-        assert c[4 * W + 2] == (3 if B > 10 else 0)
-        for v in range(2):
-            m = int(c[4 * W + v])
-            nseg = int(c[2 * v * W:2 * (v + 1) * W:2].sum())
-            for name in ("rows", "inv", "order", "perm"):
-                assert np.array_equal(N(getattr(got, name))[v, :m], getattr(want, name).numpy()[v, :m]), (me, v, name)
-            assert np.array_equal(N(got.uniq)[v, :nseg], want.uniq.numpy()[v, :nseg]), (me, v)
-        n_s = int(c[4 * W]) // 2
-        assert np.array_equal(N(got.u_loc)[:n_s], want.u_loc.numpy()[:n_s])
-        views.append((want, c))
-    # sender / receiver agreement, from the restatement's outputs: rows in wire order
+        ws = K.ShardWorkspace(W, me, B, k, nu, ni, dev)
+        K.shard_route(ws, T(ids, dev))
+        wo = O.ShardWorkspace(W, me, B, k, nu, ni)
+        O.shard_route(wo, torch.from_numpy(ids))
+        c = wo.counts.numpy()
+        assert np.array_equal(N(ws.counts), c), me
+        assert c[4] == 0 and c[5] == 0
+        n_s, n_g = wo.n_s, wo.n_g
+        nuL = (nu - me + W - 1) // W
+        ckey = N(ws.list(2)).view(np.uint32)
+        assert np.array_equal(ckey[:n_s], wo.u_loc), me
+        assert np.array_equal(ckey[n_s:n_s + n_g], nuL + wo.okey), me
+        assert np.array_equal(N(ws.list(3))[n_s:n_s + n_g], wo.osrc), me
+        assert np.array_equal(N(ws.list(4))[:, :n_s], wo.ref), me
+        assert np.array_equal(N(ws.list(5))[:, :n_s], wo.ow), me
+        assert np.array_equal(N(ws.serve)[:wo.n_serve], wo.serve.numpy()[:wo.n_serve]), me
+        assert np.all(N(ws.list(7))[n_s:n_s + n_g][wo.osrc < 0] == 1.0)
+        # solo flags: the key occurs once in the combined list and its one contribution is local
+        keys = np.concatenate((wo.u_loc.astype(np.int64), nuL + wo.okey.astype(np.int64)))
+        _, inv, cnt = np.unique(keys, return_inverse=True, return_counts=True)
+        single = cnt[inv] == 1
+        solo = N(ws.list(6))
+        assert np.array_equal(solo[0, :n_s], single[:n_s].astype(np.uint8)), me
+        want = np.zeros((2, n_s), np.uint8)
+        loc = wo.osrc >= 0
+        want[wo.osrc[loc] & 1, wo.osrc[loc] >> 1] = single[n_s:][loc]
+        assert np.array_equal(solo[1:, :n_s], want), me
+        views.append((wo, c))
+    # sender / receiver agreement, from the restatement's lists
+    niLs = [(ni - r + W - 1) // W for r in range(W)]
     for r in range(W):
-        vr, cr = views[r]
-        wire_r = vr.rows.numpy()[0][vr.order.numpy()[0, :int(cr[4 * W])]]              # rows of r's contributions, sorted
-        so = np.concatenate(([0], np.cumsum(cr[1:2 * W:2])))
-        fo = np.concatenate(([0], np.cumsum(cr[0:2 * W:2])))
+        wr, cr = views[r]
+        fo = np.concatenate(([0], np.cumsum(cr[8:8 + W])))              # fetch-buffer offsets per owner
+        go = np.concatenate(([0], np.cumsum(cr[8 + W:8 + 2 * W])))      # send-buffer offsets per owner
+        rem = wr.ow < 0
+        item = np.stack((ids[:, 1, :].reshape(-1), ids[:, 2, :].reshape(-1)))      # [part, global sample]
+        S = np.nonzero(ids[:, 0, :].reshape(-1) % W == r)[0]
         for o in range(W):
-            vo, co = views[o]
-            wire_o = vo.rows.numpy()[1][vo.order.numpy()[1, :int(co[4 * W + 1])]]
-            ro_ = np.concatenate(([0], np.cumsum(co[2 * W + 1:4 * W:2])))
-            fr = np.concatenate(([0], np.cumsum(co[2 * W:4 * W:2])))
-            assert np.array_equal(wire_r[so[o]:so[o + 1]], wire_o[ro_[r]:ro_[r + 1]]), (r, o)
-            assert np.array_equal(vr.uniq.numpy()[0, fo[o]:fo[o + 1]], vo.uniq.numpy()[1, fr[r]:fr[r + 1]]), (r, o)
+            wo_, co = views[o]
+            so = np.concatenate(([0], np.cumsum(co[8 + 2 * W:8 + 3 * W])))         # serve-list offsets per processing rank
+            ro_ = np.concatenate(([0], np.cumsum(co[8 + 3 * W:8 + 4 * W])))        # receive-buffer offsets
+            assert cr[8 + o] == co[8 + 2 * W + r] and cr[8 + W + o] == co[8 + 3 * W + r], (r, o)
+            if o == r:
+                assert cr[8 + o] == 0 and cr[8 + W + o] == 0
+                continue
+            for part in range(2):
+                sel = rem[part] & (item[part][S] % W == o)
+                seg = wr.ref[part][sel] - niLs[r] - fo[o]                # index into the rows o serves to r
+                assert np.all((seg >= 0) & (seg < cr[8 + o]))
+                served = wo_.serve.numpy()[so[r]:so[r + 1]]
+                assert np.array_equal(served[seg], item[part][S][sel] // W), (r, o, part)
+                wire = -1 - wr.ow[part][sel] - go[o]                     # position among the rows r sends to o
+                assert np.all((wire >= 0) & (wire < cr[8 + W + o]))
+                # o's entry that takes receive row ro_[r] + wire is the same (part, sample) entry
+                recv_of = {int(-1 - x): c_ for c_, x in enumerate(wo_.osrc) if x < 0}
+                E = np.nonzero(np.concatenate((item[0], item[1])) % W == o)[0]     # o's owned entries, canonical order
+                for w_, s_ in zip(wire[:50], np.nonzero(sel)[0][:50]):
+                    e = E[recv_of[int(ro_[r] + w_)]]
+                    assert e == part * W * B + S[s_], (r, o, part)
 
 
-@pytest.mark.parametrize("k", [1, 10, 30, 64, 128, 150])
-def test_bpr_item_grads(dev, k):
+def test_shard_route_refuses_bad_ids_and_overload(dev):
+    """An id out of range anywhere in the global batch, or a rank over its capacity, is reported to EVERY rank (counts [4] /
+    [5]) and the trainer refuses the batch; an overloaded batch writes no list at all (every length is reported as zero)."""
     from deeprec_amd import kernels as K
-    import _oracle_ops as O
-    rng = np.random.default_rng(k)
-    n, rows = 3001, 777
-    P = rng.standard_normal((rows, k)).astype(np.float32)
-    u_loc = rng.integers(0, rows, n).astype(np.int32)
-    g = rng.standard_normal(n).astype(np.float32)
-    order = rng.permutation(2 * n).astype(np.int32)
-    got = N(K.bpr_item_grads(T(P, dev), T(u_loc, dev), T(g, dev), T(order, dev)))
-    want = O.bpr_item_grads(*(torch.from_numpy(x) for x in (P, u_loc, g, order))).numpy()
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    from deeprec_amd import sharding as sh
+    rng = np.random.default_rng(3)
+    W, B, nu, ni, k = 4, 512, 4001, 900, 16
+    ids = np.stack((rng.integers(0, nu, (W, B)), rng.integers(0, ni, (W, B)), rng.integers(0, ni, (W, B))), 1).astype(np.int32)
+    bad = ids.copy()
+    bad[0, 0, 3], bad[W - 1, 1, 5], bad[1, 2, 7] = -1, ni, -5
+    for me in range(W):
+        ws = K.ShardWorkspace(W, me, B, k, nu, ni, dev)
+        K.shard_route(ws, T(bad, dev))
+        assert int(ws.counts[4]) == 3
+    over = ids.copy()
+    over[:, 0, :] = (over[:, 0, :] // W) * W                        # every user row lives on rank 0
+    for me in range(W):
+        ws = K.ShardWorkspace(W, me, B, k, nu, ni, dev, cap_s=B + 100, cap_g=4 * B)
+        K.shard_route(ws, T(over, dev))
+        c = N(ws.counts)
+        assert c[5] == 1 and c[0] == 0 and c[1] == 0 and c[3] == 0 and c[8 + 4 * W] == W * B
+    Pt = sh.ShardedTable(nu, k, 1, 0, dev, 2)
+    Qt = sh.ShardedTable(ni, k, 1, 0, dev, 2)
+    tr = sh.ShardedBpr(K, Pt, Qt, pipelined=False)
+    with pytest.raises(IndexError):
+        tr.route(T(bad[0, 0], dev), T(bad[0, 1], dev), T(bad[0, 2], dev))
 
 
 # ------------------------------------------------------------------ whole steps
@@ -238,6 +280,49 @@ def test_two_ranks_on_one_gpu_equal_fused_step(dev, tmp_path, world):
     for nm, y in zip(("P", "Q", "vP", "vQ"), want[:4]):
         _same(res[nm], y, nm)
     np.testing.assert_allclose(res["losses"], want[4], rtol=1e-6)
+
+
+def test_c4_size_sharded_step_world1_rccl_equals_fused_step(dev):
+    """BASELINE config 4 at full size on the sharded path: 10 M x 1 M x 128, B = 65 536, one rank with the process group
+    up (RCCL, world 1), pipelined trainer, 2 steps: tables and every optimizer slot equal the fused single-GPU step's
+    (dr_bpr_plan_f32 + dr_bpr_step_planned_f32) bit for bit, the loss sums too."""
+    import torch.distributed as dist
+    from deeprec_amd import kernels as K
+    from deeprec_amd import sharding as sh
+    import bench
+    nu, ni, k, B = 10_000_000, 1_000_000, 128, 65536
+
+    class A:
+        users, items, batch = nu, ni, B
+    batches = bench.make_batches(A, 0, dev, 3)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        Pt = sh.ShardedTable(nu, k, 1, 0, dev, 2)
+        Qt = sh.ShardedTable(ni, k, 1, 0, dev, 2)
+        Pt.init_normal_(K, 1, 0.01)
+        Qt.init_normal_(K, 2, 0.01)
+        tr = sh.ShardedBpr(K, Pt, Qt, pipelined=True)
+        tr.prefetch(*batches[0])
+        losses = [float(tr.step(_opt(K, t + 1), next_batch=batches[t + 1])) for t in range(2)]
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    P = torch.empty((nu, k), dtype=torch.float32, device=dev)
+    Q = torch.empty((ni, k), dtype=torch.float32, device=dev)
+    K.init_normal_(P, 1, 0.01)
+    K.init_normal_(Q, 2, 0.01)
+    sP = [torch.zeros_like(P), torch.zeros_like(P)]
+    sQ = [torch.zeros_like(Q), torch.zeros_like(Q)]
+    ws = K.StepWorkspace(B, k, nu, ni, K.REG_TOUCHED, dev)
+    want = []
+    for t in range(2):
+        K.bpr_plan(nu, ni, k, *batches[t], ws)
+        want.append(float(K.bpr_step(P, Q, sP, sQ, *batches[t], _opt(K, t + 1), ws, planned=True)))
+    assert losses == want
+    for got, ref, nm in ((Pt.w, P, "P"), (Qt.w, Q, "Q"), (Pt.slots[0], sP[0], "m_P"), (Pt.slots[1], sP[1], "v_P"),
+                         (Qt.slots[0], sQ[0], "m_Q"), (Qt.slots[1], sQ[1], "v_Q")):
+        assert torch.equal(got, ref), nm
 
 
 # ------------------------------------------------------------------ data-parallel evaluation
