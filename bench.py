@@ -100,7 +100,8 @@ def main():
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1 or args.sharded:
-        # --sharded on one GPU: a process group of size 1, so that every exchange still goes through RCCL
+        # --sharded on one GPU: the row-sharded trainer at world 1 (it exchanges nothing there: the fused step) with a
+        # process group of size 1 up, as in a multi-GPU job
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -235,6 +236,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timed loop runs on a stream of its own, not on the legacy default stream: with a process group up, work on the
+    # default stream is serialised against one of the side streams (hardware-queue sharing; measured at world 1 with
+    # tools/sharded_hostprof.py --pg [--own-main]: 0.199 ms per sharded step on the default stream, 0.157 ms on an explicit
+    # one that is first used AFTER the tables, the batches and the side streams exist).
+    torch.cuda.synchronize()
+    own = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(own)
+    stream = own
     for t in range(args.warmup):
         step(t)
     barrier()

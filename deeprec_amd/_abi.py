@@ -76,7 +76,7 @@ SIGNATURES = {
     "dr_bucket_order_i32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "dr_shard_bpr_bytes": (_i64, [_i32, _i64, _i32, _i64, _i64]),
     "dr_shard_bpr_list": (_i32, [_i32, _i64, _i32, _i64, _i64, _p, _i32, C.POINTER(_p)]),
-    "dr_shard_bpr_route": (_i32, [_p, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _p, _i64, _p]),
+    "dr_shard_bpr_route": (_i32, [_p, _p, _p, _p, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _p, _i64, _p, _p]),
     "dr_shard_bpr_forward": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _p, _p, _optp,
                                     _p, _i64, _p]),
     "dr_shard_bpr_finish": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _p, _optp, _p,

@@ -89,7 +89,8 @@ static int shard_layout(int world, int64_t B, int k, int64_t cap_s, int64_t cap_
 }
 
 struct RouteArgs {
-    const int32_t* ids;   // [W][3][B]
+    const int32_t* ids;   // [W][3][B]; NULL at world 1: the three lists below
+    const int32_t *u1, *i1, *j1;
     int64_t B, WB, nu, ni;
     int W, me;
     uint32_t rpo;         // rows per owner (upper bound): view keys = major * rpo + local row
@@ -103,12 +104,18 @@ struct Sample {
     bool ok;
 };
 __device__ __forceinline__ Sample read_sample(const RouteArgs& a, int64_t g) {
-    const int64_t s = g / a.B, pos = g - s * a.B;
-    const int32_t* base = a.ids + s * 3 * a.B;
     Sample x;
-    x.u = base[pos];
-    x.i = base[a.B + pos];
-    x.j = base[2 * a.B + pos];
+    if (a.ids) {
+        const int64_t s = g / a.B, pos = g - s * a.B;
+        const int32_t* base = a.ids + s * 3 * a.B;
+        x.u = base[pos];
+        x.i = base[a.B + pos];
+        x.j = base[2 * a.B + pos];
+    } else {
+        x.u = a.u1[g];
+        x.i = a.i1[g];
+        x.j = a.j1[g];
+    }
     x.ok = x.u >= 0 && x.u < a.nu && x.i >= 0 && x.i < a.ni && x.j >= 0 && x.j < a.ni;
     return x;
 }
@@ -588,18 +595,22 @@ extern "C" int32_t dr_shard_bpr_list(int32_t world, int64_t B, int32_t k, int64_
     return DR_OK;
 }
 
-// Everything about a step that depends on the ids only.  ids = [world][3][B] int32 (every rank's u, i, j).
+// Everything about a step that depends on the ids only.  ids = [world][3][B] int32 (every rank's u, i, j); at world 1
+// ids may be NULL and the batch given as its three lists u, i, j [B] (no copy into a stacked buffer).  counts_host
+// (may be NULL): pinned host memory that receives the counts by an asynchronous copy at the end of the route.
 // counts (8 + 6 world int32, dr_shard_bpr_list which = 0): [0] samples this rank processes, [1] entries of its combined key list,
 // [2] remote item entries it sends gradient rows for, [3] those plus the ones it receives, [4] samples with an id out
 // of range, [5] some rank exceeds a capacity, [6] item entries it owns, [7] gradient rows it receives; then per rank:
 // rows to fetch from it / gradient rows to send to it / rows it fetches from me / gradient rows it sends me /
 // samples it processes / item entries it owns.  No host synchronisation.
-extern "C" int32_t dr_shard_bpr_route(const int32_t* ids, int32_t world, int32_t me, int64_t B, int64_t num_user,
-                                      int64_t num_item, int32_t k, int64_t cap_s, int64_t cap_g, void* ws, int64_t ws_bytes,
+extern "C" int32_t dr_shard_bpr_route(const int32_t* ids, const int32_t* u, const int32_t* i, const int32_t* j,
+                                      int32_t world, int32_t me, int64_t B, int64_t num_user, int64_t num_item, int32_t k,
+                                      int64_t cap_s, int64_t cap_g, void* ws, int64_t ws_bytes, int32_t* counts_host,
                                       void* stream) {
     int rc = shard_args_ok(world, me, B, num_user, num_item, k, cap_s, cap_g);
     if (rc != DR_OK) return rc;
-    DR_REQUIRE(ids != nullptr && ws != nullptr && ((uintptr_t)ws % 256 == 0), "dr_shard_bpr_route: NULL / misaligned pointer");
+    DR_REQUIRE(ws != nullptr && ((uintptr_t)ws % 256 == 0), "dr_shard_bpr_route: NULL / misaligned workspace");
+    DR_REQUIRE(ids != nullptr || (world == 1 && u && i && j), "dr_shard_bpr_route: ids is NULL (u, i, j serve at world 1 only)");
     ShardLayout L;
     if (shard_layout(world, B, k, cap_s, cap_g, &L) != 0) return DR_ERR_LAUNCH;
     if (ws_bytes < L.total)
@@ -608,6 +619,9 @@ extern "C" int32_t dr_shard_bpr_route(const int32_t* ids, int32_t world, int32_t
     char* base = (char*)ws;
     RouteArgs a;
     a.ids = ids;
+    a.u1 = u;
+    a.i1 = i;
+    a.j1 = j;
     a.B = B;
     a.WB = (int64_t)world * B;
     a.nu = num_user;
@@ -654,7 +668,11 @@ extern "C" int32_t dr_shard_bpr_route(const int32_t* ids, int32_t world, int32_t
                         niL, counts, o.osrc, o.ref, o.ow, (int32_t*)(base + L.serve));
         DR_CHECK_LAUNCH("shard_vpack_kernel");
     }
-    return plan_build_shard(o.ckey, counts, o.osrc, L.cap_s, L.cap_k, a.nuL, niL, o.solo, base + L.plan, L.plan_bytes, k, st);
+    rc = plan_build_shard(o.ckey, counts, o.osrc, L.cap_s, L.cap_k, a.nuL, niL, o.solo, base + L.plan, L.plan_bytes, k, st);
+    if (rc != DR_OK) return rc;
+    if (counts_host)
+        DR_HIP(hipMemcpyAsync(counts_host, counts, (size_t)(C_LISTS + 6 * world) * 4, hipMemcpyDeviceToHost, st));
+    return DR_OK;
 }
 
 // Lookups, dots, loss; every row with one local contribution updated in place; gradient rows of remote items into

@@ -273,14 +273,28 @@ class ShardWorkspace:
         return v.view(2, self.cap_s) if which in (4, 5) else v
 
 
-def shard_route(ws, ids):
-    """dr_shard_bpr_route: ids = [world, 3, B] int32 (every rank's u, i, j).  No host synchronisation; read ws.counts
-    afterwards for the split sizes of the two row exchanges."""
-    ids = _req(ids, torch.int32, "ids", 3)
-    if tuple(ids.shape) != (ws.world, 3, ws.B):
-        raise ValueError("ids must be [%d, 3, %d]" % (ws.world, ws.B))
-    check(_abi.lib().dr_shard_bpr_route(_ptr(ids), ws.world, ws.me, ws.B, ws.num_user, ws.num_item, ws.k, ws.cap_s,
-                                        ws.cap_g, _ptr(ws.buf), ws.buf.numel(), _stream()), "dr_shard_bpr_route")
+def shard_route(ws, ids=None, uij=None, counts_host=None, stream=None):
+    """dr_shard_bpr_route: ids = [world, 3, B] int32 (every rank's u, i, j), or at world 1 uij = (u, i, j) as they are.
+    counts_host: pinned int32 tensor [8 + 6 world] that receives the counts asynchronously.  stream: raw handle of the
+    stream to enqueue on (default: torch's current one).  No host synchronisation."""
+    pu = pi = pj = None
+    if ids is not None:
+        ids = _req(ids, torch.int32, "ids", 3)
+        if tuple(ids.shape) != (ws.world, 3, ws.B):
+            raise ValueError("ids must be [%d, 3, %d]" % (ws.world, ws.B))
+    else:
+        if ws.world != 1 or uij is None:
+            raise ValueError("shard_route: ids [world, 3, B] is required at world > 1")
+        pu, pi, pj = (_i32(t, n) for t, n in zip(uij, "uij"))
+        if pu.numel() != ws.B or pi.numel() != ws.B or pj.numel() != ws.B:
+            raise ValueError("u, i, j must have %d entries" % ws.B)
+    if counts_host is not None and (counts_host.dtype != torch.int32 or counts_host.numel() < 8 + 6 * ws.world
+                                    or counts_host.is_cuda or not counts_host.is_pinned()):
+        raise ValueError("counts_host must be a pinned int32 tensor of %d entries" % (8 + 6 * ws.world))
+    check(_abi.lib().dr_shard_bpr_route(_ptr(ids), _ptr(pu), _ptr(pi), _ptr(pj), ws.world, ws.me, ws.B, ws.num_user,
+                                        ws.num_item, ws.k, ws.cap_s, ws.cap_g, _ptr(ws.buf), ws.buf.numel(),
+                                        C.c_void_p(counts_host.data_ptr()) if counts_host is not None else None,
+                                        C.c_void_p(stream) if stream is not None else _stream()), "dr_shard_bpr_route")
 
 
 def _shard_tables(ws, P, Q, slotsP, slotsQ, opt, who):
@@ -294,26 +308,29 @@ def _shard_tables(ws, P, Q, slotsP, slotsQ, opt, who):
     _slots(opt, slotsQ[0], slotsQ[1], Q, who + "(Q)")
 
 
-def shard_forward(ws, P, Q, slotsP, slotsQ, opt, fetched=None, send=None):
+def shard_forward(ws, P, Q, slotsP, slotsQ, opt, fetched=None, send=None, checked=False):
     """dr_shard_bpr_forward on the batch routed into ws.  fetched [>= rows fetched, k] / send [>= rows sent, k]: the
-    exchange buffers (None at world 1)."""
-    _shard_tables(ws, P, Q, slotsP, slotsQ, opt, "shard_forward")
-    for name, t in (("fetched", fetched), ("send", send)):
-        if t is not None and _req(t, torch.float32, name, 2).shape[1] != ws.k:
-            raise ValueError("%s must have %d columns" % (name, ws.k))
-    if ws.world > 1 and (fetched is None or send is None or send.shape[0] < 2 * ws.cap_s or fetched.shape[0] < 2 * ws.cap_s):
-        raise ValueError("shard_forward: fetched / send need 2 * cap_s = %d rows" % (2 * ws.cap_s))
+    exchange buffers (None at world 1).  checked: the caller validated these very tensors on an earlier call."""
+    if not checked:
+        _shard_tables(ws, P, Q, slotsP, slotsQ, opt, "shard_forward")
+        for name, t in (("fetched", fetched), ("send", send)):
+            if t is not None and _req(t, torch.float32, name, 2).shape[1] != ws.k:
+                raise ValueError("%s must have %d columns" % (name, ws.k))
+        if ws.world > 1 and (fetched is None or send is None or send.shape[0] < 2 * ws.cap_s
+                             or fetched.shape[0] < 2 * ws.cap_s):
+            raise ValueError("shard_forward: fetched / send need 2 * cap_s = %d rows" % (2 * ws.cap_s))
     check(_abi.lib().dr_shard_bpr_forward(_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), _ptr(Q), _ptr(slotsQ[0]),
                                           _ptr(slotsQ[1]), *ws._sizes(), _ptr(fetched), _ptr(send), C.byref(opt),
                                           _ptr(ws.buf), ws.buf.numel(), _stream()), "dr_shard_bpr_forward")
 
 
-def shard_finish(ws, P, Q, slotsP, slotsQ, opt, received=None):
+def shard_finish(ws, P, Q, slotsP, slotsQ, opt, received=None, checked=False):
     """dr_shard_bpr_finish; returns the device scalar loss sum of the samples this rank processed."""
-    _shard_tables(ws, P, Q, slotsP, slotsQ, opt, "shard_finish")
-    if ws.world > 1 and (received is None or _req(received, torch.float32, "received", 2).shape[1] != ws.k
-                         or received.shape[0] < ws.cap_g):
-        raise ValueError("shard_finish: received needs cap_g = %d rows of %d columns" % (ws.cap_g, ws.k))
+    if not checked:
+        _shard_tables(ws, P, Q, slotsP, slotsQ, opt, "shard_finish")
+        if ws.world > 1 and (received is None or _req(received, torch.float32, "received", 2).shape[1] != ws.k
+                             or received.shape[0] < ws.cap_g):
+            raise ValueError("shard_finish: received needs cap_g = %d rows of %d columns" % (ws.cap_g, ws.k))
     check(_abi.lib().dr_shard_bpr_finish(_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), _ptr(Q), _ptr(slotsQ[0]),
                                          _ptr(slotsQ[1]), *ws._sizes(), _ptr(received), C.byref(opt), _ptr(ws.loss),
                                          _ptr(ws.buf), ws.buf.numel(), _stream()), "dr_shard_bpr_finish")

@@ -83,17 +83,16 @@ class ShardedTable:
 _SIDE = {}
 
 
-def _side_stream(device):
+def _side_streams(device, n=4):
     key = (device.type, device.index)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
+        _SIDE[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _SIDE[key]
 
 
 class BprRoute:
     """One routed batch: its workspace slot and, after finish(), the split sizes of the two row exchanges."""
-    __slots__ = ("slot", "ws", "n_fetch", "n_serve", "n_send", "n_recv", "send_f", "recv_f", "send_g", "recv_g", "ready",
-                 "counted")
+    __slots__ = ("slot", "ws", "n_fetch", "n_serve", "n_send", "n_recv", "send_f", "recv_f", "send_g", "recv_g", "ready")
 
 
 class ShardedBpr:
@@ -110,6 +109,7 @@ class ShardedBpr:
     ops.shard_caps); a batch beyond them is refused by every rank together."""
 
     SLOTS = 3       # route workspaces: the batch that runs + two routed ahead
+    N_SIDE = 2      # side streams the routes alternate on
 
     def __init__(self, ops, P, Q, group=None, route_group=None, pipelined=None, caps=None):
         if P.world != Q.world or P.rank != Q.rank or P.k != Q.k:
@@ -124,10 +124,14 @@ class ShardedBpr:
         if route_group is None and self.pipelined and self.cuda and self.collective and self.world > 1:
             route_group = dist.new_group()          # collective call: every rank constructs its trainer
         self.route_group = route_group if route_group is not None else group
-        self.side = _side_stream(P.w.device) if (self.cuda and self.pipelined) else None
+        # two side streams: the routes of batches t+1 and t+2 run beside each other and beside step t (a route is a chain
+        # of short launches that takes about two step times next to the bandwidth-saturating forward kernel)
+        self.sides = _side_streams(P.w.device)[:self.N_SIDE] if (self.cuda and self.pipelined) else None
+        self._routes = 0
         self.caps = caps
         self.B = None
         self._pending = []          # routed batches, oldest first (at most SLOTS - 1)
+        self._unchecked = None
         self._next_slot = 0
 
     # ---- buffers, once -----------------------------------------------------------------------------------
@@ -136,26 +140,31 @@ class ShardedBpr:
         dev = P.w.device
         cs, cg = self.caps if self.caps is not None else ops.shard_caps(W, B)
         self.B = B
-        self.ws = [ops.ShardWorkspace(W, self.rank, B, P.k, P.rows, Q.rows, dev, cs, cg) for _ in range(self.SLOTS)]
-        self.ids = [torch.empty((W, 3, B), dtype=torch.int32, device=dev) for _ in range(self.SLOTS)]
-        self.mine = [torch.empty((3, B), dtype=torch.int32, device=dev) for _ in range(self.SLOTS)] if W > 1 else None
-        nc = 8 + 6 * W
-        self.counts_host = [torch.empty(nc, dtype=torch.int32, pin_memory=self.cuda) for _ in range(self.SLOTS)]
-        self.counted = [torch.cuda.Event() for _ in range(self.SLOTS)] if self.cuda else None
+        n = self.SLOTS
+        self.ws = [ops.ShardWorkspace(W, self.rank, B, P.k, P.rows, Q.rows, dev, cs, cg) for _ in range(n)]
+        if W > 1:
+            self.ids = [torch.empty((W, 3, B), dtype=torch.int32, device=dev) for _ in range(n)]
+            self.mine = [torch.empty((3, B), dtype=torch.int32, device=dev) for _ in range(n)]
+        self.counts_host = [torch.zeros(8 + 6 * W, dtype=torch.int32, pin_memory=self.cuda) for _ in range(n)]
+        if self.cuda:
+            self.ev_routed = [torch.cuda.Event() for _ in range(n)]     # the route's kernels and its counts copy are done
+            self.ev_free = [torch.cuda.Event() for _ in range(n)]       # the caller's stream no longer reads the slot
         if W > 1:
             f32 = dict(dtype=torch.float32, device=dev)
             self.serve_buf = torch.empty((cg, P.k), **f32)        # rows the peers fetch from this rank
             self.fetch_buf = torch.empty((2 * cs, P.k), **f32)    # rows this rank fetches
             self.send_buf = torch.empty((2 * cs, P.k), **f32)     # gradient rows out
             self.recv_buf = torch.empty((cg, P.k), **f32)         # gradient rows in
+        self._checked = False
 
     # ---- ids only --------------------------------------------------------------------------------------
     def route(self, u, i, j):
         return self._route_finish(self._route_begin(u, i, j))
 
-    def _route_begin(self, u, i, j):
-        """The part of a route that needs no host synchronisation: the id all-gather, dr_shard_bpr_route and the
-        asynchronous copy of its counts to pinned host memory."""
+    def _route_begin(self, u, i, j, stream=None):
+        """The part of a route that needs no host synchronisation: the id all-gather and dr_shard_bpr_route, which ends
+        with the asynchronous copy of its counts to pinned host memory.  stream: raw handle to enqueue on (world 1 only;
+        default and world > 1: torch's current stream)."""
         ops, W = self.ops, self.world
         B = u.numel()
         if i.numel() != B or j.numel() != B or B < 1:
@@ -170,27 +179,25 @@ class ShardedBpr:
         rt.slot = self._next_slot
         self._next_slot = (self._next_slot + 1) % self.SLOTS
         rt.ws = self.ws[rt.slot]
-        ids = self.ids[rt.slot]
+        rt.ready = None
         if W > 1:
-            mine = self.mine[rt.slot]
+            ids, mine = self.ids[rt.slot], self.mine[rt.slot]
             torch.stack((u.reshape(-1), i.reshape(-1), j.reshape(-1)), out=mine)
             _gather_ids(ids, mine, self.route_group)               # the one collective of a route
+            ops.shard_route(rt.ws, ids, counts_host=self.counts_host[rt.slot])
         else:
-            torch.stack((u.reshape(-1), i.reshape(-1), j.reshape(-1)), out=ids[0])
-        ops.shard_route(rt.ws, ids)
-        self.counts_host[rt.slot].copy_(rt.ws.counts, non_blocking=True)
-        rt.counted = None
-        if self.cuda:
-            rt.counted = self.counted[rt.slot]
-            rt.counted.record()
-        rt.ready = None
+            # one rank: the batch's own three lists are the global batch (no stacked copy)
+            ops.shard_route(rt.ws, uij=(u, i, j), counts_host=self.counts_host[rt.slot], stream=stream)
         return rt
 
     def _route_finish(self, rt):
         """The host synchronisation of a route: its counts (split sizes of the two row exchanges, refused batches)."""
         W = self.world
-        if rt.counted is not None:
-            rt.counted.synchronize()                               # the one host synchronisation of a route
+        if self.cuda:
+            if rt.ready is None:                                   # routed on the caller's stream
+                rt.ready = self.ev_routed[rt.slot]
+                rt.ready.record()
+            rt.ready.synchronize()                                 # the one host synchronisation of a route
         c = self.counts_host[rt.slot].tolist()
         # the ids are replicated, so every rank sees the same numbers: a bad batch on ONE rank is refused by ALL ranks
         # here, before any of them enters a row exchange
@@ -200,10 +207,11 @@ class ShardedBpr:
             raise RuntimeError("sharded BPR step: a rank would process more than %d samples or own more than %d item "
                                "entries of this batch (per-rank loads: %s samples, %s entries); pass larger caps"
                                % (rt.ws.cap_s, rt.ws.cap_g, c[8 + 4 * W:8 + 5 * W], c[8 + 5 * W:8 + 6 * W]))
-        rt.send_f, rt.send_g = c[8:8 + W], c[8 + W:8 + 2 * W]      # per owner: distinct rows to fetch, gradient rows out
-        rt.recv_f, rt.recv_g = c[8 + 2 * W:8 + 3 * W], c[8 + 3 * W:8 + 4 * W]   # per processing rank
-        rt.n_fetch, rt.n_send = sum(rt.send_f), sum(rt.send_g)
-        rt.n_serve, rt.n_recv = sum(rt.recv_f), sum(rt.recv_g)
+        if W > 1:
+            rt.send_f, rt.send_g = c[8:8 + W], c[8 + W:8 + 2 * W]  # per owner: distinct rows to fetch, gradient rows out
+            rt.recv_f, rt.recv_g = c[8 + 2 * W:8 + 3 * W], c[8 + 3 * W:8 + 4 * W]   # per processing rank
+            rt.n_fetch, rt.n_send = sum(rt.send_f), sum(rt.send_g)
+            rt.n_serve, rt.n_recv = sum(rt.recv_f), sum(rt.recv_g)
         return rt
 
     # ---- table values ----------------------------------------------------------------------------------
@@ -211,37 +219,47 @@ class ShardedBpr:
         ops, P, Q, g = self.ops, self.P, self.Q, self.group
         ws = rt.ws
         sP, sQ = (P.slot(0), P.slot(1)), (Q.slot(0), Q.slot(1))
+        ok = self._checked                          # tensors validated on the first step; they never change
+        self._checked = True
         if self.world == 1:
             # the fused single-GPU step: nothing to fetch, nothing to send
-            ops.shard_forward(ws, P.w, Q.w, sP, sQ, opt)
-            return ops.shard_finish(ws, P.w, Q.w, sP, sQ, opt)
+            ops.shard_forward(ws, P.w, Q.w, sP, sQ, opt, checked=ok)
+            return ops.shard_finish(ws, P.w, Q.w, sP, sQ, opt, checked=ok)
         # distinct remote item rows <- owners (the owners run K1 on their shard, before any of this step's updates)
         served = self.serve_buf[:rt.n_serve]
         ops.gather_into(Q.w, ws.serve[:rt.n_serve], served)
         _a2a(self.fetch_buf[:rt.n_fetch], served, rt.send_f, rt.recv_f, g)
         # lookups, dots, loss; rows with one local contribution updated in place; gradient rows of remote items -> send_buf
-        ops.shard_forward(ws, P.w, Q.w, sP, sQ, opt, self.fetch_buf, self.send_buf)
+        ops.shard_forward(ws, P.w, Q.w, sP, sQ, opt, self.fetch_buf, self.send_buf, checked=ok)
         _a2a(self.recv_buf[:rt.n_recv], self.send_buf[:rt.n_send], rt.recv_g, rt.send_g, g)
         # every other row of both tables; contributions in ascending global batch position, local or received
-        return ops.shard_finish(ws, P.w, Q.w, sP, sQ, opt, self.recv_buf)
+        return ops.shard_finish(ws, P.w, Q.w, sP, sQ, opt, self.recv_buf, checked=ok)
 
-    # ---- one batch ahead -------------------------------------------------------------------------------
+    # ---- batches ahead ---------------------------------------------------------------------------------
     def _begin_ahead(self, u, i, j):
         """Enqueue the sync-free part of a route (on the side stream when pipelined).  The side stream first waits for
         an event recorded HERE on the caller's current stream, so ids produced by earlier work on that stream are
-        complete before the route reads them (and the workspace slot it reuses has been read by the step before the
-        one running now) -- and nothing enqueued on the caller's stream later delays the route."""
-        if self.side is None:
+        complete before the route reads them, and the workspace slot it takes has been read by its last step -- and
+        nothing enqueued on the caller's stream later delays the route."""
+        if self.sides is None:
             return self._route_begin(u, i, j)
-        ready = torch.cuda.Event()
-        ready.record()                              # on the caller's current stream (no Stream object built: ~8 us each)
-        self.side.wait_event(ready)
+        side = self.sides[self._routes % len(self.sides)]
+        self._routes += 1
+        slot = self._next_slot if self.B is not None else 0
+        if self.B is None:
+            self._allocate(u.numel())
+        free = self.ev_free[slot]
+        free.record()                               # on the caller's current stream
+        side.wait_event(free)
         for t in (u, i, j):
-            t.record_stream(self.side)              # the caller may drop the batch right after step()
-        with torch.cuda.stream(self.side):
-            rt = self._route_begin(u, i, j)
-            rt.ready = torch.cuda.Event()
-            rt.ready.record(self.side)
+            t.record_stream(side)                   # the caller may drop the batch right after step()
+        if self.world == 1:
+            rt = self._route_begin(u, i, j, stream=side.cuda_stream)         # no stream context: ~30 us of host time
+        else:
+            with torch.cuda.stream(side):
+                rt = self._route_begin(u, i, j)
+        rt.ready = self.ev_routed[rt.slot]
+        rt.ready.record(side)
         return rt
 
     def prefetch(self, u, i, j):
@@ -253,18 +271,36 @@ class ShardedBpr:
 
     def step(self, opt, next_batch=None):
         """Run the oldest routed batch; `next_batch` = (u, i, j) is routed meanwhile (behind the ones already waiting).
-        Order on the host: (1) the host reads the counts of the batch to run -- routed one or two steps ago, so its id
-        kernels have long finished; (2) the sync-free route of next_batch goes to the side stream, where it waits only
+        Order on the host: (1) at world > 1 the host reads the counts of the batch to run (split sizes of its exchanges)
+        -- routed one or two steps ago; (2) the sync-free route of next_batch goes to the side stream, where it waits only
         for what the caller's stream held at that moment (the previous step: the last reader of the workspace slot it
         takes); (3) this batch's kernels and exchanges are enqueued."""
         if not self._pending:
             raise RuntimeError("ShardedBpr.step: no routed batch (call prefetch first)")
-        rt = self._route_finish(self._pending.pop(0))
+        if self._unchecked is not None:             # world 1: the counts of the batch that ran in the previous call
+            done, self._unchecked = self._unchecked, None
+            self._route_finish(done)
+        rt = self._pending.pop(0)
+        if self.world > 1 or not self.cuda:
+            self._route_finish(rt)                  # the split sizes of the exchanges: the host has to see them
         if next_batch is not None:
             self._pending.append(self._begin_ahead(*next_batch))
         if rt.ready is not None:
             rt.ready.wait()                         # the caller's current stream waits for the route's side-stream work
-        return self.run(rt, opt)
+        loss = self.run(rt, opt)
+        if self.world == 1 and self.cuda:
+            # One rank exchanges nothing, so the host needs no number from the route before it enqueues the step: the
+            # step waits for the route on the device, and the counts are read at the next call (flush() reads them now).
+            # A batch with ids out of range is therefore reported one call late at world 1; its valid samples have been
+            # applied, the invalid ones contributed nothing.
+            self._unchecked = rt
+        return loss
+
+    def flush(self):
+        """Check the counts of the last batch that ran (world 1 defers that check by one call, see step())."""
+        if self._unchecked is not None:
+            done, self._unchecked = self._unchecked, None
+            self._route_finish(done)
 
 
 def sharded_bpr_step(ops, P, Q, u, i, j, opt, group=None):

@@ -464,7 +464,9 @@ int32_t dr_seq_dot_loss_f32(const float* W, const float* bias, int64_t num_item,
  * ws: dr_shard_bpr_bytes(...), 256-byte aligned; it holds the route, the plan, the stash and the per-sample losses of ONE
  * batch (route a batch ahead into a second workspace).  Nothing is allocated and no host synchronisation happens inside.
  *
- * dr_shard_bpr_route    ids only: 2 launches + (world > 1: sort of the remote entries + 2) + the plan (7).
+ * dr_shard_bpr_route    ids only: 2 launches + (world > 1: sort of the remote entries + 2) + the plan (7).  At world 1 ids
+ *                       may be NULL and the batch given as u, i, j [B]; counts_host (may be NULL): pinned host memory
+ *                       that receives the counts (below) by an asynchronous copy on `stream`.
  * dr_shard_bpr_list     device address of a list inside ws.  which = 0: counts (int32 [8 + 6 world]: [0] samples processed here, [1] entries
  *                       of the combined list, [2] gradient rows sent, [3] sent + received, [4] samples of the GLOBAL batch
  *                       with an id out of range, [5] some rank over a capacity, [6] item entries owned, [7] gradient rows
@@ -479,8 +481,9 @@ int32_t dr_seq_dot_loss_f32(const float* W, const float* bias, int64_t num_item,
 int64_t dr_shard_bpr_bytes(int32_t world, int64_t B, int32_t k, int64_t cap_s, int64_t cap_g);
 int32_t dr_shard_bpr_list(int32_t world, int64_t B, int32_t k, int64_t cap_s, int64_t cap_g, void* ws, int32_t which,
                           void** ptr);
-int32_t dr_shard_bpr_route(const int32_t* ids, int32_t world, int32_t me, int64_t B, int64_t num_user, int64_t num_item,
-                           int32_t k, int64_t cap_s, int64_t cap_g, void* ws, int64_t ws_bytes, void* stream);
+int32_t dr_shard_bpr_route(const int32_t* ids, const int32_t* u, const int32_t* i, const int32_t* j, int32_t world,
+                           int32_t me, int64_t B, int64_t num_user, int64_t num_item, int32_t k, int64_t cap_s,
+                           int64_t cap_g, void* ws, int64_t ws_bytes, int32_t* counts_host, void* stream);
 int32_t dr_shard_bpr_forward(float* P, float* Pslot0, float* Pslot1, float* Q, float* Qslot0, float* Qslot1,
                              int32_t world, int32_t me, int64_t B, int64_t num_user, int64_t num_item, int32_t k,
                              int64_t cap_s, int64_t cap_g, const float* fetched, float* send, const dr_opt_params* opt,

@@ -42,8 +42,10 @@ class ShardWorkspace:
         self.loss = torch.zeros(1, dtype=torch.float32)
 
 
-def shard_route(ws, ids):
+def shard_route(ws, ids=None, uij=None, counts_host=None, stream=None):
     """dr_shard_bpr_route (include/deeprec_amd.h): both roles of rank ws.me from the replicated id lists."""
+    if ids is None:
+        ids = torch.stack([t.reshape(-1) for t in uij]).reshape(1, 3, -1)
     g = _n(ids).astype(np.int64)
     W, me, B = ws.world, ws.me, ws.B
     WB = W * B
@@ -111,6 +113,8 @@ def shard_route(ws, ids):
     c[0], c[1], c[2], c[3], c[6], c[7] = n_s, n_s + n_g, len(V0), len(V0) + len(V1), n_g, len(V1)
     c[5] = int((hp > ws.cap_s).any() or (ho > ws.cap_g).any())
     ws.counts = torch.from_numpy(c.astype(np.int32))
+    if counts_host is not None:
+        counts_host.copy_(ws.counts)
     ws.nuL, ws.niL = nuL, niL
 
 
@@ -119,7 +123,7 @@ def gather_into(table, ids, out):
     return out
 
 
-def shard_forward(ws, P, Q, slotsP, slotsQ, opt, fetched=None, send=None):
+def shard_forward(ws, P, Q, slotsP, slotsQ, opt, fetched=None, send=None, checked=False):
     """dr_shard_bpr_forward without its in-place updates (shard_finish below applies every row: the same sums in the
     same order -- that the kernels' split between forward and tail changes nothing is what the GPU tests check)."""
     Pn, Qn = _n(P), _n(Q)
@@ -136,7 +140,7 @@ def shard_forward(ws, P, Q, slotsP, slotsQ, opt, fetched=None, send=None):
             out[-1 - ws.ow[part][rem]] = (cf[rem, None] * pu[rem]).astype(np.float32)
 
 
-def shard_finish(ws, P, Q, slotsP, slotsQ, opt, received=None):
+def shard_finish(ws, P, Q, slotsP, slotsQ, opt, received=None, checked=False):
     n_slots = {ro.OPT_SGD: 0, ro.OPT_ADAM: 2, ro.OPT_ADAGRAD: 1, ro.OPT_RMSPROP: 2}[opt.kind]
     s_idx, prt = ws.osrc >> 1, ws.osrc & 1
     local = ws.osrc >= 0
