@@ -30,6 +30,7 @@ _optp = C.POINTER(OptParams)
 SIGNATURES = {
     "dr_last_error": (C.c_char_p, []),
     "dr_version": (_i32, []),
+    "dr_init": (_i32, [_i32]),
     "dr_gather_f32": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _p, _i32, _p, _p]),
     "dr_scale_rows_f32": (_i32, [_p, _i64, _i32, _p, _p, _i64, _p, _p]),
     "dr_segment_plan_bytes": (_i64, [_i64, _i32]),

@@ -3,6 +3,13 @@
 
 namespace dr {
 thread_local bool g_no_side_streams = false;
+static thread_local Helpers g_helpers[32];
+Helpers* helpers() {
+    int dev = 0;
+    if (g_no_side_streams || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    return g_helpers[dev].ready ? &g_helpers[dev] : nullptr;
+}
+int static_scratch_init();   // pairwise.hip: device address of dr_bpr_step_static_f32's scratch array
 char* last_error_buf() {
     static thread_local char buf[512] = {0};
     return buf;
@@ -92,6 +99,33 @@ extern "C" int32_t dr_adam_tick_f32(float* state, float lr, float beta1, float b
     DR_LAUNCH(dr::adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, lr, beta1, beta2);
     DR_CHECK_LAUNCH("dr_adam_tick_f32");
     return DR_OK;
+}
+
+// Everything the library ever creates or looks up, in one explicit call per (host thread, device): two helper streams
+// and five events for the steps that overlap their plan with the forward kernel, and the device address of the static
+// scratch of dr_bpr_step_static_f32.  Idempotent.  No other entry point creates a stream or an event or allocates.
+extern "C" int32_t dr_init(int32_t device) {
+    DR_REQUIRE(device >= 0 && device < 32, "dr_init: device %d out of range [0, 32)", device);
+    int cur = -1;
+    DR_HIP(hipGetDevice(&cur));
+    if (cur != device) DR_HIP(hipSetDevice(device));
+    dr::Helpers& h = dr::g_helpers[device];
+    int rc = DR_OK;
+    if (!h.ready) {
+        hipError_t e = hipStreamCreateWithFlags(&h.plan, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h.seg, hipStreamNonBlocking);
+        hipEvent_t* evs[5] = {&h.fork, &h.q_ready, &h.p_ready, &h.seg_fork, &h.seg_join};
+        for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(evs[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            snprintf(dr::last_error_buf(), 512, "dr_init: %s", hipGetErrorString(e));
+            rc = DR_ERR_LAUNCH;
+        } else {
+            h.ready = true;
+        }
+    }
+    if (rc == DR_OK) rc = dr::static_scratch_init();
+    if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+    return rc;
 }
 
 extern "C" const char* dr_last_error(void) { return dr::last_error_buf(); }

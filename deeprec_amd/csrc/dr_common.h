@@ -61,9 +61,19 @@ bool prof_slot(const char* name, hipEvent_t* e0, hipEvent_t* e1);
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                    \
     } while (0)
 
-// Set (per host thread) while an entry point that must not create HIP objects is running (dr_bpr_step_static_f32):
+// Set (per host thread) while an entry point that must not use helper streams is running (dr_bpr_step_static_f32):
 // the helper-stream providers then hand back the caller's stream.  Defined in abi.hip.
 extern thread_local bool g_no_side_streams;
+
+// Helper streams / events of the calling host thread on the current device: created by dr_init() ONLY (abi.hip) -- no
+// entry point creates a HIP object.  helpers() returns NULL until dr_init() has run on this thread for this device;
+// the steps then run on the caller's stream alone (same results, no overlap of plan and forward kernel).
+struct Helpers {
+    hipStream_t plan = nullptr, seg = nullptr;                    // plan beside the forward kernel; long-segment passes
+    hipEvent_t fork = nullptr, q_ready = nullptr, p_ready = nullptr, seg_fork = nullptr, seg_join = nullptr;
+    bool ready = false;
+};
+Helpers* helpers();
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 

@@ -395,30 +395,22 @@ __global__ __launch_bounds__(256) void bpr_qcoef_kernel(const float* __restrict_
     }
 }
 
-// Helper stream on which the segment plans of a step are built while the forward kernel runs on the caller's
-// stream (they depend on the batch ids only).  One per host thread and device, created on first use; fork/join
-// is done with events, so the caller still sees a single in-order stream (also under graph capture).
+// Helper stream on which the segment plan of a step is built while the forward kernel runs on the caller's stream
+// (it depends on the batch ids only): dr_init()'s objects (dr_common.h: helpers()); fork / join with events, so the
+// caller still sees a single in-order stream (also under graph capture).  Without dr_init(): the caller's stream alone.
 struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, q_ready = nullptr, p_ready = nullptr;
+    hipStream_t s;
+    hipEvent_t fork, q_ready, p_ready;
 };
-static SideStream* side_stream() {
-    static thread_local SideStream side[32];
+static bool side_stream(SideStream* out) {
     static const bool off = DR_EXP_ENV("DR_NO_OVERLAP") != nullptr;
-    if (off || g_no_side_streams) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    SideStream& x = side[dev];
-    if (!x.s) {
-        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) { x.s = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&x.q_ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&x.p_ready, hipEventDisableTiming) != hipSuccess) {
-            x.s = nullptr;
-            return nullptr;
-        }
-    }
-    return &x;
+    Helpers* h = off ? nullptr : helpers();
+    if (!h) return false;
+    out->s = h->plan;
+    out->fork = h->fork;
+    out->q_ready = h->q_ready;
+    out->p_ready = h->p_ready;
+    return true;
 }
 
 // ---- pointwise forward: GMF BCE (gmf.py:66-75) / MF squared error (mf.py:50-55,96-97) ----
@@ -795,7 +787,8 @@ static int bpr_step_impl(float* P, float* Pslot0, float* Pslot1, int64_t num_use
     const bool any = B > 0 || reg_mode == DR_REG_DENSE;
     // Fork (mode 0): the id lists and both segment plans depend on the batch ids only, so they are built on the
     // helper stream while the forward kernel runs here; the updates join on events.
-    SideStream* side = (mode == 0 && B > 0) ? side_stream() : nullptr;
+    SideStream side_obj;
+    SideStream* side = (mode == 0 && B > 0 && side_stream(&side_obj)) ? &side_obj : nullptr;
     hipStream_t ps = side ? side->s : st;
     if (side) {
         DR_HIP(hipEventRecord(side->fork, st));
@@ -881,18 +874,25 @@ static __device__ __align__(256) unsigned char scratch[DR_STATIC_WS_BYTES];
 
 namespace dr {
 static void* g_scratch_ptr[32] = {nullptr};
-// device address of this device's `scratch`; looked up on the first call on each device (the library has no init call)
-static int static_scratch(void** out) {
+// device address of this device's `scratch`: looked up by dr_init() (abi.hip), or -- for callers that never called it --
+// on the first static step on each device
+int static_scratch_init() {
     int dev = -1;
     DR_HIP(hipGetDevice(&dev));
     DR_REQUIRE(dev >= 0 && dev < 32, "dr_bpr_step_static_f32: device index %d out of range", dev);
-    void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
-    if (!p) {
-        DR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-        DR_REQUIRE(p != nullptr && ((uintptr_t)p % 256 == 0), "dr_bpr_step_static_f32: bad scratch address");
-        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);  // racing threads store the same address
-    }
-    *out = p;
+    if (__atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE)) return DR_OK;
+    void* p = nullptr;
+    DR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    DR_REQUIRE(p != nullptr && ((uintptr_t)p % 256 == 0), "dr_bpr_step_static_f32: bad scratch address");
+    __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);  // racing threads store the same address
+    return DR_OK;
+}
+static int static_scratch(void** out) {
+    int rc = static_scratch_init();
+    if (rc != DR_OK) return rc;
+    int dev = -1;
+    DR_HIP(hipGetDevice(&dev));
+    *out = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
     return DR_OK;
 }
 }  // namespace dr
@@ -916,7 +916,7 @@ extern "C" int32_t dr_bpr_step_static_f32(float* P, float* Pslot0, float* Pslot1
     int rc = static_scratch(&ws);
     if (rc != DR_OK) return rc;
     // 3B <= 4096 keys: the plan is ONE workgroup (plan_small_kernel), no device-wide sort; no helper streams or events
-    // are created or used (g_no_side_streams), nothing is allocated or freed.  The plan kernels write every header field
+    // are used (g_no_side_streams), nothing is created, allocated or freed.  The plan kernels write every header field
     // and every partial row before it is read, so the previous call's contents need no clearing.
     g_no_side_streams = true;
     rc = bpr_step_impl(P, Pslot0, Pslot1, num_user, Q, Qslot0, Qslot1, num_item, k, u, i, j, B, opt, 0, loss_out, ws,

@@ -840,6 +840,14 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
         // store + ds_or still in flight (no s_waitcnt in the latch), and the row's owner -- another wave -- then read the
         // candidate word without the bit: lost top-K entries for the rows written last (found with tools/_dbg, 6-12 of
         // 300 users wrong, different ones every run).
+        // Round 3, looked at again in the ISA of all 29 instantiations (hipcc of ROCm 7.2, tools/check_barriers.py): the
+        // compiler now puts `s_waitcnt lgkmcnt(0)` in front of EVERY s_barrier of these kernels with or without this
+        // intrinsic (the generated code is identical, instruction for instruction, when both intrinsics are deleted; so is
+        // it without the vmcnt(0) intrinsic above and without the s_setprio pair) -- the latch that lacked the wait belonged
+        // to an earlier shape of this loop and cannot be reproduced from the present source.  The intrinsic stays as the
+        // statement of intent; what GUARDS the property is `make check` (every path into every s_barrier of every
+        // instantiation must pass an lgkmcnt(0) wait after its last LDS store / atomic) and
+        // test_score_kernel_instantiations_repeatable_and_exact.
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __syncthreads();  // A: tile t-1's candidates are visible, every wave is done with the item tile in LDS
 #endif

@@ -695,36 +695,22 @@ __global__ __launch_bounds__(SMALL_T) void plan_small_kernel(Src src, int n,
 // ---------------------------------------------------------------------------------------
 // segment sum (+ optimizer application)
 // ---------------------------------------------------------------------------------------
-// helper stream of the calling host thread for `main`'s device; returns `main` when it cannot be had
+// helper stream (dr_init()'s, dr_common.h: helpers()) for the long-segment passes; returns `main` when there is none
 hipStream_t seg_side_stream(hipStream_t main, hipEvent_t* fork, hipEvent_t* join) {
-    struct Side {
-        hipStream_t s = nullptr;
-        hipEvent_t fork = nullptr, join = nullptr;
-    };
-    static thread_local Side side[32];
     static const bool off = DR_EXP_ENV("DR_NO_OVERLAP") != nullptr;
     static const bool always = DR_EXP_ENV("DR_OVERLAP") != nullptr;
-    int dev = 0;
-    if (off || g_no_side_streams || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return main;
+    Helpers* h = off ? nullptr : helpers();
+    if (!h) return main;
     if (!always) {
         // Launched eagerly the fork / join costs four event calls (~45 us of host time per fused step, measured)
         // and buys no GPU time; as a parallel branch of a captured graph it is free on the host and worth ~5 %.
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(main, &cs) != hipSuccess || cs != hipStreamCaptureStatusActive) return main;
     }
-    Side& x = side[dev];
-    if (!x.s) {
-        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
-            x.s = nullptr;
-            return main;
-        }
-    }
-    if (hipEventRecord(x.fork, main) != hipSuccess || hipStreamWaitEvent(x.s, x.fork, 0) != hipSuccess) return main;
-    *fork = x.fork;
-    *join = x.join;
-    return x.s;
+    if (hipEventRecord(h->seg_fork, main) != hipSuccess || hipStreamWaitEvent(h->seg, h->seg_fork, 0) != hipSuccess) return main;
+    *fork = h->seg_fork;
+    *join = h->seg_join;
+    return h->seg;
 }
 
 // per-contribution metadata in SORTED order, so that the segment kernels read it with plain sequential loads

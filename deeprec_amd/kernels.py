@@ -28,6 +28,18 @@ def _stream():
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
+_INITED = set()
+
+
+def init(device=None):
+    """dr_init for the current (or given) device: the library's helper streams / events and the static scratch address.
+    Called by the workspace constructors; idempotent."""
+    dev = torch._C._cuda_getDevice() if device is None else torch.device(device).index
+    if dev not in _INITED:
+        check(_abi.lib().dr_init(int(dev)), "dr_init")
+        _INITED.add(dev)
+
+
 def _on_current_device(t, name):
     """Launches go to the CURRENT device's current stream: a tensor of another GPU would be read through that GPU's
     pointer on the wrong stream (or fault).  One process drives one GPU here; anything else is refused."""
@@ -437,6 +449,7 @@ class StepWorkspace:
 
     def __init__(self, B, k, num_user, num_item, reg_mode, device):
         self.key = (int(B), int(k), int(num_user), int(num_item), int(reg_mode))
+        init(device)
         need = check(_abi.lib().dr_pairwise_step_bytes(B, k, num_user, num_item, reg_mode), "dr_pairwise_step_bytes")
         self.buf = torch.empty(need, dtype=torch.uint8, device=device)
         self.loss = torch.zeros(1, dtype=torch.float32, device=device)
@@ -497,6 +510,7 @@ def bpr_step_static(P, Q, slotsP, slotsQ, u, i, j, opt, loss_out):
     allocates nothing (loss_out: caller's float32 [1] tensor).  B <= 1024, k <= 128, no DR_REG_DENSE; calls that
     overlap on one GPU race (include/deeprec_amd.h)."""
     B = _check_pq(P, Q, u, (("u", u), ("i", i), ("j", j)))
+    init(P.device)
     _slots(opt, slotsP[0], slotsP[1], P, "bpr_step_static(P)")
     _slots(opt, slotsQ[0], slotsQ[1], Q, "bpr_step_static(Q)")
     if _req(loss_out, torch.float32, "loss_out").numel() < 1:

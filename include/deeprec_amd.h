@@ -77,6 +77,13 @@ typedef struct dr_opt_params {
                                can be captured into a hipGraph.  NULL = use `reg`.                      */
 } dr_opt_params;
 
+/* The one call that creates anything (no counterpart in the reference): for the calling host thread and `device`, two
+ * helper streams and five events (steps that build their plan beside the forward kernel: dr_bpr_step_f32; long-segment
+ * passes under graph capture) and the device address of dr_bpr_step_static_f32's scratch array.  Idempotent.  Every
+ * other entry point creates no stream or event and allocates nothing; without dr_init() the steps run on the caller's
+ * stream alone (identical results). */
+int32_t dr_init(int32_t device);
+
 const char* dr_last_error(void);
 int32_t dr_version(void);
 
@@ -184,7 +191,9 @@ int32_t dr_bpr_step_planned_f32(float* P, float* Pslot0, float* Pslot1, int64_t 
  * and creates no streams or events.  Limits: B <= DR_STATIC_MAX_B, k <= DR_STATIC_MAX_K, opt->reg_mode !=
  * DR_REG_DENSE (that mode needs table-sized dense gradients); anything beyond is DR_ERR_ARG / DR_ERR_WORKSPACE with
  * a message.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads)
- * race -- serialise them.  The array keeps the last call's contents; every field is rewritten before it is read. */
+ * race -- serialise them.  The array keeps the last call's contents; every field is rewritten before it is read.
+ * The array's device address is looked up by dr_init(device) (or, failing that, by the first call on a device): call
+ * dr_init() before capturing this entry point into a graph. */
 #define DR_STATIC_MAX_B 1024 /* the reference's BPRMF batch size (bprmf.py:41) */
 #define DR_STATIC_MAX_K 128
 int32_t dr_bpr_step_static_f32(float* P, float* Pslot0, float* Pslot1, int64_t num_user, float* Q,

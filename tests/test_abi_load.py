@@ -51,3 +51,16 @@ def test_argument_errors_without_gpu():
     assert lib.dr_gather_f32(None, 10, 4, None, 0, 32, None, 0, None, None) == 0   # empty id list is a no-op
     opt = _abi.OptParams(kind=7)
     assert lib.dr_dense_update_f32(None, None, None, None, 4, C.byref(opt), None) == -1
+
+
+def test_isa_no_barrier_with_lds_store_in_flight():
+    """`make check` (deeprec_amd/csrc/Makefile): the device assembly of every scoring-kernel instantiation has an
+    lgkmcnt(0) wait on every path between an LDS store / atomic and the next s_barrier (round 2's lost top-K entries),
+    and the checker flags the hand-written negative fixture.  Needs hipcc only (cross-compiles without a GPU)."""
+    import shutil
+    import subprocess
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "deeprec_amd", "csrc"), "check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ", 0 violations" in r.stdout and "1 violations" in r.stdout

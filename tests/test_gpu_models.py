@@ -378,6 +378,12 @@ def _seq_dataset(tmp_path, rng, nu=25, ni=40, L=3, T=2):
     return train, test
 
 
+def f32(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
 def test_seq_models_train_and_evaluate(dev, tmp_path):
     """AttRec / Caser / PRME drop-ins (testSeqRec.py:45-70 flow): prepare, one epoch, test(); the evaluators'
     numbers equal the oracle ranking of the models' own predict() scores."""
@@ -396,18 +402,39 @@ def test_seq_models_train_and_evaluate(dev, tmp_path):
         quiet(m.train, train)
         res = quiet(m.test, test)
         assert np.isfinite(res["HR@50"]) and 0 <= res["MRR"] <= 1
-        # oracle ranking of predict() scores
+        # (a) EXACT: the oracle ranking of the scores in the arithmetic each evaluator documents -- evaluate1: the
+        # reference's own numpy float32 operation order (SeqRecMetrics.py:122-123) from getUserParam / getItemParam;
+        # evaluate_caser and PRME's evaluate: the k-ordered fmaf chain of the scoring kernel
         ni = train.num_item
-        hr, mrr = [], []
-        for uu in m.test_users:
-            s = m.predict([uu] * ni, list(range(ni)))
+        users = list(m.test_users)
+        if cls is AttRec:
+            uf, sf, _, _ = m.getUserParam(m.test_users)
+            i1, i2, _ = m.getItemParam(np.expand_dims(np.arange(ni), axis=1))
+            a = np.float32(m.alpha)
+            S = ro.numpy_order_scores(2, f32(uf), f32(i1), f32(sf), f32(i2), a, np.float32(1 - a))
+        elif cls is Caser:
+            uf = m.getUserParam(m.test_users)
+            itf, b = m.getItemParam(np.expand_dims(np.arange(ni), axis=1))
+            S = co.score_matrix(f32(uf), f32(itf), 0, bias=f32(b).reshape(-1))
+        else:
+            ops = m.seq_eval_operands(users)
+            S = co.score_matrix(f32(ops["U"]), f32(ops["I"]), 2, f32(ops["U2"]), f32(ops["I2"]), ops["alpha"])
+        hr, mrr, hr_p, mrr_p = [], [], [], []
+        for r, uu in enumerate(users):
             cand = m.neg_items[uu]
             masked = np.setdiff1d(np.arange(ni), cand)
-            _, _, ranks = ro.topk_and_ranks(s, masked, np.unique(m.test_data[uu]), 50)
-            h, mm, _ = seq_user_metrics(sorted(int(r) for r in ranks if r >= 0), len(m.test_data[uu]), len(cand), 50)
+            tg = np.unique(m.test_data[uu])
+            _, _, ranks = ro.topk_and_ranks(S[r], masked, tg, 50)
+            h, mm, _ = seq_user_metrics(sorted(int(x) for x in ranks if x >= 0), len(m.test_data[uu]), len(cand), 50)
             hr.append(h), mrr.append(mm)
-        # the fused kernels score in the expanded form: allow the rare near-tie reordering
-        assert abs(res["HR@50"] - np.mean(hr)) <= 0.05 and abs(res["MRR"] - np.mean(mrr)) <= 0.02, cls.__name__
+            # (b) the same from the model's own predict() (PRME.py:226-236 and friends: direct per-pair arithmetic)
+            sp_ = m.predict([uu] * ni, list(range(ni)))
+            _, _, ranks = ro.topk_and_ranks(sp_, masked, tg, 50)
+            h, mm, _ = seq_user_metrics(sorted(int(x) for x in ranks if x >= 0), len(m.test_data[uu]), len(cand), 50)
+            hr_p.append(h), mrr_p.append(mm)
+        assert res["HR@50"] == float(np.mean(hr)) and res["MRR"] == float(np.mean(mrr)), cls.__name__
+        # predict() rounds differently from the evaluator's form: only a near-tie may move
+        assert abs(res["HR@50"] - np.mean(hr_p)) <= 0.05 and abs(res["MRR"] - np.mean(mrr_p)) <= 0.02, cls.__name__
 
 
 def test_nnmf_runs(dev):

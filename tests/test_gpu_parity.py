@@ -539,6 +539,50 @@ def test_score_topk_leave_one_out_is_repeatable(dev):
             assert torch.equal(idx, first[0]) and torch.equal(val, first[1])
 
 
+@pytest.mark.parametrize("ntgt", [1, 3])            # 1: score_kernel_t1 (leave-one-out); 3: score_kernel (several held-out items)
+@pytest.mark.parametrize("kind", [0, 1])            # 0: plain dot (no affine epilogue); 1: -|p - q|^2 (affine epilogue)
+@pytest.mark.parametrize("k", [62, 64, 126, 128, 254, 256])   # 32 / 64 / 128 k-steps, with and without float4 rows
+def test_score_kernel_instantiations_repeatable_and_exact(dev, k, kind, ntgt):
+    """Every register-panel instantiation of the scoring kernels (k-steps 32 / 64 / 128 x vector rows x affine epilogue
+    x leave-one-out / general), on the shape that exposed round 2's lost-candidate race: one 64-item tile per split, a
+    ragged last tile, more than 32 masked train items inside one tile (the mask list overflows into the row words) and
+    forced ties.  Four runs must agree with the oracle and with each other.  (The ISA side of the same guarantee is
+    `make -C deeprec_amd/csrc check`: no s_barrier with an LDS store in flight, tools/check_barriers.py.)"""
+    from deeprec_amd import kernels as K
+    Nu, Ni, K_ = 200, 64 * 31 + 37, 10
+    rng = np.random.default_rng(k * 10 + kind * 3 + ntgt)
+    U, I, train, tgt = _eval_case(rng, Nu, Ni, k, 40, 0, std=0.3 if kind == 0 else 0.1)
+    for u in range(0, Nu, 3):                           # 48 consecutive masked items: > 32 in one 64-item tile
+        lo = int(rng.integers(0, Ni - 48))
+        train[u] = np.unique(np.concatenate((train[u], np.arange(lo, lo + 48))))
+    tgt = []
+    for u in range(Nu):
+        t = rng.integers(0, Ni, ntgt if u % 5 else 0)
+        if u % 7 == 0 and len(t) and len(train[u]):
+            t[0] = train[u][0]                          # a masked held-out item -> rank -1
+        if u % 4 == 1 and len(t):
+            t[-1] = (Ni // 3, Ni // 2, Ni // 5)[u % 3]  # one of the three tied items
+        tgt.append(np.unique(t))
+    tp, ti = _csr(train)
+    gp, gi = _csr(tgt)
+    scores = co.score_matrix(U, I, kind)
+    tU, tI = T(U, dev), T(I, dev)
+    tr, tg = (T(tp, dev), T(ti, dev)), (T(gp, dev), T(gi, dev))
+    first = None
+    for _ in range(4):
+        idx, val, rank = K.score_topk(tU, tI, K_, score_kind=kind, train=tr, targets=tg)
+        if first is None:
+            first = (idx, val, rank)
+            _check_selection(scores, train, tgt, K_, N(idx), N(val), N(rank))
+        else:
+            assert torch.equal(idx, first[0]) and torch.equal(val, first[1]) and torch.equal(rank, first[2])
+    # the band instantiations (dr_score_rank_exact_f32) on the same inputs: repeatable and equal to numpy's order
+    want = _exact_ranks(ro.numpy_order_scores(kind, U, I), train, tgt)
+    for _ in range(2):
+        r = N(K.score_rank_exact(tU, tI, tg, score_kind=kind, train=tr))
+        assert np.array_equal(r, want)
+
+
 @pytest.mark.parametrize("kind", [1, 2])
 def test_score_topk_distances(dev, kind):
     """CML (cml.py:151-153) and AttRec/PRME (SeqRecMetrics.py:122-123, alpha=0.2) scores."""
