@@ -162,6 +162,7 @@ class SegmentPlan:
 
     def __init__(self, ids, rows, workspace=None, k_max=128):
         ids, bits = _ids(ids, "ids")
+        init()
         self.n = ids.numel()
         self.rows = int(rows)
         self.k_max = int(k_max)
