@@ -32,6 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=25,
+                    help="timed windows of --steps steps each, back to back; ms_per_step is the median window (the first "
+                         "window is the contract's 'exactly K steps' and is reported too)")
     ap.add_argument("--users", type=int, default=10_000_000)
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--k", type=int, default=128)
@@ -46,6 +49,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--sharded", action="store_true",
                     help="run the row-sharded (multi-GPU) step even at --gpus 1, to price its exchange logic without a fabric")
+    ap.add_argument("--no-stream-calibration", action="store_true",
+                    help="skip the untimed trial that picks the main / side streams (see calibrate_streams)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="build each batch's segment plans inside its own step (dr_bpr_step_f32) instead of one batch ahead")
     return ap.parse_args()
@@ -139,47 +144,58 @@ def main():
         nb = len(batches)
         wss = [K.StepWorkspace(B, k, args.users, args.items, K.REG_TOUCHED, device) for _ in range(nb)]
         ws = wss[0]
-        side = torch.cuda.Stream(device=device)
         pipelined = not args.no_pipeline
         # The segment plan of a batch depends on its ids only and is a chain of ~17 short dependent launches: beside the
         # bandwidth-saturating forward kernel that chain takes ~2x its stand-alone 100 us, longer than the step itself
         # (0.15 ms), so ONE plan in flight made the step plan-bound (tools/eager_probe.py: 0.222 ms).  DEPTH plans are
         # kept in flight instead, each on its own stream: batch b + DEPTH is planned while batch b runs.
         DEPTH = 1 if args.graph else 2
-        sides = [torch.cuda.Stream(device=device) for _ in range(DEPTH)]
+        sides = [torch.cuda.Stream(device=device) for _ in range(max(DEPTH, 1))]
+        side = sides[0]
+
+        def set_sides(new):
+            sides[:] = new[:len(sides)]
         ev_end = [torch.cuda.Event() for _ in range(nb)]
         ev_plan = [torch.cuda.Event() for _ in range(nb)]
         started = {"end": set(), "plan": set()}
 
+        calls = [K.PlannedBprStep(P, Q, sP, sQ, *batches[b], wss[b]) for b in range(nb)]   # arguments validated once
+        cur_stream = {}
+
         def eager_step(b):
-            """One step on resident batch b.  Pipelined: the id lists / segment plan of batch b + DEPTH (they depend
-            on its ids only) are built on another stream while this step's kernels run; every step still does all of
-            its own work -- one plan, one step -- inside the timed region."""
+            """One step on resident batch b.  Pipelined: the segment plan of batch b + DEPTH (it depends on its ids only)
+            is built on another stream while this step's kernels run; every step still does all of its own work -- one
+            plan, one step -- inside the timed region."""
             u, i, j = batches[b]
             if adam:
                 adam_state.tick()
                 opt_dev.alpha_dev = adam_state.alpha.data_ptr()
             if not pipelined:
                 return K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b])
-            cur = torch.cuda.current_stream()
             if DEPTH == 1:
+                cur = torch.cuda.current_stream()
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     K.bpr_plan(args.users, args.items, k, *batches[(b + 1) % nb], wss[(b + 1) % nb])
                 loss = K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b], planned=True)
                 cur.wait_stream(side)
                 return loss
+            # host path kept lean (a 0.15 ms step leaves no room for stream context managers: raw stream handles, events
+            # recorded on explicit streams, arguments validated once)
+            cur = cur_stream.get("s")
+            if cur is None or cur_stream["id"] != torch._C._cuda_getCurrentRawStream(device.index):
+                cur = cur_stream["s"] = torch.cuda.current_stream()
+                cur_stream["id"] = cur.cuda_stream
             nxt = (b + DEPTH) % nb
             sd = sides[b % DEPTH]
             if (b - 1) % nb in started["end"]:
                 sd.wait_event(ev_end[(b - 1) % nb])     # the workspace of batch `nxt` was last read by an earlier step
-            with torch.cuda.stream(sd):
-                K.bpr_plan(args.users, args.items, k, *batches[nxt], wss[nxt])
-                ev_plan[nxt].record(sd)
-                started["plan"].add(nxt)
+            calls[nxt].plan(sd.cuda_stream)
+            ev_plan[nxt].record(sd)
+            started["plan"].add(nxt)
             if b in started["plan"]:
                 cur.wait_event(ev_plan[b])
-            loss = K.bpr_step(P, Q, sP, sQ, u, i, j, opt_dev, wss[b], planned=True)
+            loss = calls[b].step(opt_dev, cur_stream["id"])
             ev_end[b].record(cur)
             started["end"].add(b)
             return loss
@@ -189,6 +205,7 @@ def main():
                 K.bpr_plan(args.users, args.items, k, *batches[b], wss[b])
             launch = ("eager, plans %d batches ahead on %d side streams" % (DEPTH, DEPTH)) if DEPTH > 1 else \
                 "eager, plans one batch ahead on a second stream"
+            launch += "; launches per step: plan 7 (3 x [histogram, ranked scatter] + finish) + step 3 (fused forward, tail, combine)"
 
         def step(t):
             return eager_step(t % nb)
@@ -226,39 +243,50 @@ def main():
         trainer = sh.ShardedBpr(K, Pt, Qt)
         trainer.prefetch(*batches[0])
         trainer.prefetch(*batches[1])
-        launch = "eager; routes (id all-gather, the rank's lists and plan) two batches ahead on a second stream"
+        launch = ("eager; routes (id all-gather, the rank's lists and plan) two batches ahead on two side streams; launches per "
+                  "step: route %d + step %d, collectives %d" % ((9, 3, 0) if world == 1 else (17, 4, 3)))
 
         def step(t):
             return trainer.step(opt_for(t + 1), next_batch=batches[(t + 2) % len(batches)])
+
+        def set_sides(new):
+            trainer.sides = list(new[:trainer.N_SIDE])
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The timed loop runs on a stream of its own, not on the legacy default stream: with a process group up, work on the
-    # default stream is serialised against one of the side streams (hardware-queue sharing; measured at world 1 with
-    # tools/sharded_hostprof.py --pg [--own-main]: 0.199 ms per sharded step on the default stream, 0.157 ms on an explicit
-    # one that is first used AFTER the tables, the batches and the side streams exist).
-    torch.cuda.synchronize()
-    own = torch.cuda.Stream(device=device)
-    torch.cuda.set_stream(own)
-    stream = own
+    done = 0
+    stream_note = "default stream"
+    if not args.no_stream_calibration and not (args.graph and not args.no_graph):
+        done, stream_note = calibrate_streams(step, set_sides, device)
+        stream = torch.cuda.current_stream()
     for t in range(args.warmup):
-        step(t)
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(args.steps):
-        loss = step(args.warmup + t)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        step(done + t)
+    done += args.warmup
+    # R windows of exactly --steps steps, each bracketed by barrier + synchronize on both sides and reduced with MAX over
+    # the ranks; the driver's --steps 20 is 3 ms of GPU time, one sample of a distribution -- the median window is the figure
+    wins = []
+    for _ in range(max(1, args.windows)):
+        barrier()
+        t0 = time.perf_counter()
+        for t in range(args.steps):
+            loss = step(done + t)
+        barrier()
+        dt = time.perf_counter() - t0
+        done += args.steps
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        wins.append(dt)
     last_loss = float(loss.item())
+    srt = sorted(wins)
+    dt = srt[len(srt) // 2]
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
+    timed_s = sum(wins)
 
     result = {
         "metric": "train samples/s + top-10 eval users/s; embedding gather GB/s vs HBM peak",
@@ -272,6 +300,12 @@ def main():
                    "optimizer": args.opt, "reg_mode": "touched", "launch": launch,
                    "parallelism": "single" if world == 1 and not args.sharded else "row-sharded x%d (all-to-all)" % world},
         "last_loss_sum": last_loss,
+        "windows": len(wins), "ms_per_step_first_window": wins[0] / args.steps * 1e3,
+        "ms_per_step_min_max": [srt[0] / args.steps * 1e3, srt[-1] / args.steps * 1e3],
+        "timed_seconds_total": timed_s,
+        "timing": "median of %d back-to-back windows of %d steps, each between barrier + synchronize, MAX over ranks"
+                  % (len(wins), args.steps),
+        "streams": stream_note,
     }
 
     if (world > 1 or args.sharded) and not args.no_extras:
@@ -287,6 +321,43 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def calibrate_streams(step, set_sides, device, pool_n=6, trial_steps=40):
+    """Untimed trial before the warm-up: which streams the step and its side work (plans / routes of the next batches) run
+    on.  HIP multiplexes a process's streams onto 4 hardware queues and places them when they are first used; which ones
+    end up sharing a queue depends on how many streams torch, RCCL and this library created before, and the pipelined step
+    is sensitive to it -- measured on one box with one tree: 0.152 / 0.169 / 0.180 ms per fused step and 0.157 / 0.200 ms
+    per sharded step for different, equally legitimate choices (a direct test for queue sharing between two streams -- a
+    long copy on one, a tiny kernel on the other -- did not predict which).  So a few (main, side, side) triples from a small pool are each run
+    for `trial_steps` real steps and the fastest is kept.  Every rank tries the same triples in the same order (the steps
+    contain collectives at world > 1).  Returns (steps consumed, description)."""
+    pool = [torch.cuda.Stream(device=device) for _ in range(pool_n)]
+    triples = [(0, 1, 2), (1, 2, 3), (2, 3, 4), (3, 4, 5), (0, 2, 4), (1, 3, 5), (4, 5, 0), (5, 0, 1)]
+    t, best, log = 0, None, []
+    for tr in triples:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(pool[tr[0]])
+        set_sides([pool[tr[1]], pool[tr[2]]])
+        for _ in range(8):
+            step(t)
+            t += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(trial_steps):
+            step(t)
+            t += 1
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / trial_steps * 1e3
+        log.append(round(ms, 4))
+        if best is None or ms < best[0]:
+            best = (ms, tr)
+    pick = best[1]          # per process: every rank keeps its own fastest triple
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(pool[pick[0]])
+    set_sides([pool[pick[1]], pool[pick[2]]])
+    return t, "main / side streams picked by an untimed trial of %d triples x %d steps (ms per step: %s; kept %s)" % (
+        len(triples), trial_steps, log, list(pick))
 
 
 def sharded_eval(args, K, sh, Pt, Qt, world, rank, device, barrier):
@@ -332,11 +403,14 @@ ROCPROF_NAMES = {   # live name -> kernel name in `rocprofv3 --kernel-trace --st
     "bpr_forward_update_kernel": "dr::bpr_forward_update_1col_kernel<4, 32, 1>",
     "bpr_tail_kernel": "dr::bpr_tail_kernel<4, 32, 1>",
     "bpr_tail_combine_kernel": "dr::bpr_tail_combine_kernel<4, 32, 1>",
+    "lsd_hist_kernel": "dr::lsd_hist_kernel<...>", "lsd_scatter_kernel": "dr::lsd_scatter_kernel<...>",
+    "bpr_finish_kernel": "dr::bpr_finish_kernel<dr::FinBpr>",
     "seg_update_kernel<item side>": "dr::seg_update_kernel<4, 32, 2, 1>",
     "seg_update_kernel<user side>": "dr::seg_update_kernel<4, 32, 1, 1>",
     "seg_long_partial_kernel": "dr::seg_long_partial_kernel<4, 32>",
     "seg_long_combine_kernel": "dr::seg_long_combine_kernel<4, 32>",
 }
+TRAFFIC_FILE = "r03_pmc_traffic.json"       # this round's PMC summary (tools/pmc_traffic.py)
 LONG_SEG = 4        # deeprec_amd/csrc/segment.hip: segments with more contributions take the two-pass path
 SEG_CHUNK = 32      # DR_SEG_CHUNK
 
@@ -428,14 +502,15 @@ def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step,
     # HBM-side bytes per launch: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, one pass each, corrected as
     # MI355X_MICROARCH.md prescribes) over tools/step_loop.py -- the same kernels on the same batches, collected in a
     # SEPARATE profiler run and committed under profiles/; not measured by this process
-    traffic, traffic_src = {}, None
-    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        tp_path = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(tp_path):
-            with open(tp_path) as f:
-                traffic = json.load(f).get("kernels", {})
-            traffic_src = "profiles/" + cand
-            break
+    # the CURRENT round's file or nothing: a stale profile must not dress up as this tree's traffic
+    tp_path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    if not os.path.exists(tp_path):
+        raise SystemExit("bench.py: profiles/%s is missing -- collect it with tools/run_round_checks.sh (two rocprofv3 --pmc "
+                         "passes over tools/step_loop.py + tools/pmc_traffic.py) before the extras can report `traffic`"
+                         % TRAFFIC_FILE)
+    with open(tp_path) as f:
+        traffic = json.load(f).get("kernels", {})
+    traffic_src = "profiles/" + TRAFFIC_FILE
     kern = {}
     for nm, ts in prof.items():
         calls, t = len(ts), sum(ts) / len(ts)

@@ -476,8 +476,9 @@ def _check_pq(P, Q, u, ids):
     return B
 
 
-def bpr_plan(num_user, num_item, k, u, i, j, ws):
-    """Build the id lists and segment plans of batch (u, i, j) into ws (for bpr_step(..., planned=True))."""
+def bpr_plan(num_user, num_item, k, u, i, j, ws, stream=None):
+    """Build the id lists and segment plans of batch (u, i, j) into ws (for bpr_step(..., planned=True)).
+    stream: raw handle of the stream to enqueue on (default: torch's current one)."""
     B = u.numel()
     for name, t in (("u", u), ("i", i), ("j", j)):
         if _i32(t, name).numel() != B:
@@ -485,7 +486,42 @@ def bpr_plan(num_user, num_item, k, u, i, j, ws):
     if ws.key[:4] != (B, int(k), int(num_user), int(num_item)):
         raise ValueError("StepWorkspace was sized for %s" % (ws.key,))
     check(_abi.lib().dr_bpr_plan_f32(num_user, num_item, k, _ptr(u), _ptr(i), _ptr(j), B, ws.key[4], _ptr(ws.buf),
-                                     ws.buf.numel(), _stream()), "dr_bpr_plan_f32")
+                                     ws.buf.numel(), C.c_void_p(stream) if stream is not None else _stream()),
+          "dr_bpr_plan_f32")
+
+
+class PlannedBprStep:
+    """One (tables, batch, workspace) combination of the planned fused step with its arguments validated ONCE: a step
+    loop over resident batches then pays one ctypes call per plan and per step (bench.py; the wrappers above re-check
+    shapes and dtypes on every call, ~15 us of a 150 us step)."""
+
+    def __init__(self, P, Q, slotsP, slotsQ, u, i, j, ws):
+        B = _check_pq(P, Q, u, (("u", u), ("i", i), ("j", j)))
+        for sl, t, nm in ((slotsP, P, "P"), (slotsQ, Q, "Q")):
+            for x in sl:
+                if x is not None and _req(x, torch.float32, "slot of " + nm).shape != t.shape:
+                    raise ValueError("optimizer slots must be shaped like their table")
+        if ws.key[:4] != (B, P.shape[1], P.shape[0], Q.shape[0]):
+            raise ValueError("StepWorkspace was sized for %s" % (ws.key,))
+        self.keep = (P, Q, slotsP, slotsQ, u, i, j, ws)
+        self.ws = ws
+        lib = _abi.lib()
+        self._plan, self._step = lib.dr_bpr_plan_f32, lib.dr_bpr_step_planned_f32
+        self._pa = (P.shape[0], Q.shape[0], P.shape[1], _ptr(u), _ptr(i), _ptr(j), B, ws.key[4], _ptr(ws.buf), ws.buf.numel())
+        self._sa = (_ptr(P), _ptr(slotsP[0]), _ptr(slotsP[1]), P.shape[0], _ptr(Q), _ptr(slotsQ[0]), _ptr(slotsQ[1]),
+                    Q.shape[0], P.shape[1], _ptr(u), _ptr(i), _ptr(j), B)
+        self._tail = (_ptr(ws.loss), _ptr(ws.buf), ws.buf.numel())
+
+    def plan(self, stream):
+        """dr_bpr_plan_f32 on the raw stream handle `stream`."""
+        check(self._plan(*self._pa, C.c_void_p(stream)), "dr_bpr_plan_f32")
+
+    def step(self, opt, stream):
+        """dr_bpr_step_planned_f32 on the raw stream handle `stream`; returns the device scalar loss."""
+        if opt.reg_mode != self.ws.key[4]:
+            raise ValueError("StepWorkspace was sized for reg_mode %d" % self.ws.key[4])
+        check(self._step(*self._sa, C.byref(opt), *self._tail, C.c_void_p(stream)), "dr_bpr_step_planned_f32")
+        return self.ws.loss
 
 
 def bpr_step(P, Q, slotsP, slotsQ, u, i, j, opt, ws=None, planned=False):

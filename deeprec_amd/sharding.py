@@ -80,14 +80,8 @@ class ShardedTable:
             self.w[l0:l0 + part.shape[0]].copy_(part)
 
 
-_SIDE = {}
-
-
-def _side_streams(device, n=4):
-    key = (device.type, device.index)
-    if key not in _SIDE:
-        _SIDE[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
-    return _SIDE[key]
+def _side_streams(device, n):
+    return [torch.cuda.Stream(device=device) for _ in range(n)]
 
 
 class BprRoute:
@@ -105,6 +99,9 @@ class ShardedBpr:
     Every rank passes a batch of the SAME length (the all-gather is fixed-size), the same on every call.
     group: communicator of the row / gradient exchanges; route_group: communicator of the id all-gather (created
     here when the step is pipelined on GPUs, because the two run concurrently on different streams).
+    `sides` (the streams the routes alternate on) may be replaced between steps after a device synchronisation: which
+    streams share a hardware queue is decided by the HIP runtime, and the step time depends on it (bench.py picks them
+    by trial).
     caps = (cap_s, cap_g): the most samples a rank may process / item entries it may own per step (default
     ops.shard_caps); a batch beyond them is refused by every rank together."""
 
@@ -126,7 +123,7 @@ class ShardedBpr:
         self.route_group = route_group if route_group is not None else group
         # two side streams: the routes of batches t+1 and t+2 run beside each other and beside step t (a route is a chain
         # of short launches that takes about two step times next to the bandwidth-saturating forward kernel)
-        self.sides = _side_streams(P.w.device)[:self.N_SIDE] if (self.cuda and self.pipelined) else None
+        self.sides = _side_streams(P.w.device, self.N_SIDE) if (self.cuda and self.pipelined) else None
         self._routes = 0
         self.caps = caps
         self.B = None

@@ -1,5 +1,5 @@
 """Summarise rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, one pass each) of tools/step_loop.py into
-profiles/r02_pmc_traffic.json (or the name given as third argument): mean HBM-side bytes per launch for each library kernel.
+profiles/r03_pmc_traffic.json (or the name given as third argument): mean HBM-side bytes per launch for each library kernel.
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $REPO/gpurun_out/pmc_fetch -o f --output-format csv -- python $REPO/tools/step_loop.py
@@ -56,7 +56,7 @@ def main():
         out["kernels"][k] = {"fetch_bytes": fb, "write_bytes": wb,
                              "hbm_bytes": (fb or 0) + (wb or 0) if (fb is not None and wb is not None) else None,
                              "launches": [len(fs), len(wsz)]}
-    name = sys.argv[3] if len(sys.argv) > 3 else "r02_pmc_traffic.json"
+    name = sys.argv[3] if len(sys.argv) > 3 else "r03_pmc_traffic.json"
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)

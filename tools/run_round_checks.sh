@@ -1,14 +1,29 @@
+# Round-end evidence, one gpurun call: GPU tests, the bench line, rocprofv3 kernel stats of the same command, the two PMC
+# passes behind roofline.traffic, the sharded world-1 line and its kernel stats.  Outputs under gpurun_out/; the
+# summaries to keep are copied into profiles/r03_* afterwards.
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gputests_b.log 2>&1 || { tail -30 gpurun_out/gputests_b.log; exit 1; }
-tail -3 gpurun_out/gputests_b.log
-timeout -k 10 400 python bench.py --steps 200 --warmup 10 > gpurun_out/bench_r2_b.json 2> gpurun_out/bench_r2_b.err
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gputests_r3.log 2>&1 || { tail -30 gpurun_out/gputests_r3.log; exit 1; }
+tail -3 gpurun_out/gputests_r3.log
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o b -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python $R/tools/step_loop.py > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o w -- python $R/tools/step_loop.py > $R/gpurun_out/pmc_write.log 2>&1
 cd $R
-python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write r02_pmc_traffic.json > gpurun_out/pmc_traffic.log 2>&1
-cp profiles/r02_pmc_traffic.json gpurun_out/
+python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write r03_pmc_traffic.json > gpurun_out/pmc_traffic.log 2>&1
+cp profiles/r03_pmc_traffic.json gpurun_out/
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_r3.json 2> gpurun_out/bench_r3.err || { tail -20 gpurun_out/bench_r3.err; exit 1; }
+timeout -k 10 300 python bench.py --sharded --steps 20 --warmup 5 --no-cpu-baseline 2> gpurun_out/bench_r3_sharded.err | tail -1 > gpurun_out/bench_r3_sharded.json
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o b -- python $R/bench.py --steps 20 --warmup 5 --windows 5 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sharded -o s -- python $R/bench.py --sharded --steps 20 --warmup 5 --windows 5 --no-cpu-baseline --no-extras > $R/gpurun_out/prof_sharded.log 2>&1
+cd $R
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/bench_r3.json'))
+print('fused', d['ms_per_step'], d['ms_per_step_min_max'], d['value'], 'roofline', d['roofline']['frac'], 'step', d['step_roofline']['frac'])
+print('scatter', d['scatter_add']['frac_hbm_peak_planned'], d['scatter_add']['frac_hbm_peak_with_plan'], 'eval', d['eval']['frac_mfma_f32_peak'])
+s = json.load(open('gpurun_out/bench_r3_sharded.json'))
+print('sharded w1', s['ms_per_step'], s['ms_per_step_min_max'], s['value'])
+PY
 echo done

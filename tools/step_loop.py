@@ -1,5 +1,5 @@
 """Run a few fused BPR steps of the bench workload (C4) -- the command profiled by the rocprofv3 --pmc passes
-whose per-kernel HBM traffic is summarised in profiles/r01_pmc_traffic.json (tools/pmc_traffic.py)."""
+whose per-kernel HBM traffic is summarised in profiles/r03_pmc_traffic.json (tools/pmc_traffic.py)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
