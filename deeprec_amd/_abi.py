@@ -75,6 +75,9 @@ SIGNATURES = {
     "dr_sample_negatives_excl_i32": (_i32, [_p, _i64, _i32, _i32, _i64, _i64, C.c_uint64, C.c_uint64, _p, _p]),
     "dr_bucket_order_bytes": (_i64, [_i64]),
     "dr_bucket_order_i32": (_i32, [_p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "dr_step_route_keys_i32": (_i32, [_p, _i32, _i32, _i64, _p, _i32, _p, _p, _p, _p]),
+    "dr_rows_pack_f32": (_i32, [_p, _i64, _i32, _p, _i32, _i64, _p, _p, _i32, _p, _i64, _p]),
+    "dr_rows_unpack_f32": (_i32, [_p, _i64, _i32, _p, _i32, _i64, _p, _p, _i32, _p, _i64, _p]),
     "dr_shard_bpr_bytes": (_i64, [_i32, _i64, _i32, _i64, _i64]),
     "dr_shard_bpr_list": (_i32, [_i32, _i64, _i32, _i64, _i64, _p, _i32, C.POINTER(_p)]),
     "dr_shard_bpr_route": (_i32, [_p, _p, _p, _p, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _p, _i64, _p, _p]),

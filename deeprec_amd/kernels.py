@@ -245,6 +245,58 @@ def gather_into(table, ids, out):
     return out
 
 
+# ------------------------------------------------------------------ one route per step (csrc/wire.hip)
+ROUTE_MAX_LISTS, WIRE_MAX_SEG = 16, 64
+
+
+def _i64_array(values):
+    return (C.c_int64 * len(values))(*[int(v) for v in values])
+
+
+def step_route_keys(ids_all, me, list_start):
+    """dr_step_route_keys_i32: ids_all int32 [world, n_tot] (every rank's concatenated id lists), list_start = host
+    offsets of the lists inside one rank's part (len n_lists + 1).  Returns (keys_mine [n_tot], keys_owned
+    [world * n_tot], local_rows [world * n_tot]) for bucket_order(..., n_lists * world)."""
+    ids_all = _req(ids_all, torch.int32, "ids_all", 2)
+    W, n_tot = ids_all.shape
+    nl = len(list_start) - 1
+    dev = ids_all.device
+    km = torch.empty(n_tot, dtype=torch.int32, device=dev)
+    ko = torch.empty(W * n_tot, dtype=torch.int32, device=dev)
+    loc = torch.empty(W * n_tot, dtype=torch.int32, device=dev)
+    check(_abi.lib().dr_step_route_keys_i32(_ptr(ids_all), W, int(me), n_tot, _i64_array(list_start), nl, _ptr(km),
+                                            _ptr(ko), _ptr(loc), _stream()), "dr_step_route_keys_i32")
+    return km, ko, loc
+
+
+def _wire_args(src_or_dst, idx, n, seg_start, seg_off, flat, name):
+    t = _req(src_or_dst, torch.float32, name)
+    if t.dim() not in (1, 2):
+        raise ValueError("%s must be [rows] or [rows, k]" % name)
+    flat = _req(flat, torch.float32, "flat", 1)
+    if idx is not None and _i32(idx, "idx").numel() != n:
+        raise ValueError("idx must have one entry per row moved")
+    if len(seg_start) != len(seg_off) + 1:
+        raise ValueError("seg_start needs one more entry than seg_off")
+    return t, (1 if t.dim() == 1 else t.shape[1]), flat
+
+
+def rows_pack(src, idx, n, seg_start, seg_off, flat, idx_bias=0):
+    """dr_rows_pack_f32: rows src[idx[e] - idx_bias] (idx None: src[e]), e < n, into the segments of the wire buffer."""
+    src, k, flat = _wire_args(src, idx, n, seg_start, seg_off, flat, "src")
+    check(_abi.lib().dr_rows_pack_f32(_ptr(src), src.shape[0], k, _ptr(idx), int(idx_bias), int(n), _i64_array(seg_start),
+                                      _i64_array(seg_off), len(seg_off), _ptr(flat), flat.numel(), _stream()),
+          "dr_rows_pack_f32")
+
+
+def rows_unpack(flat, idx, n, seg_start, seg_off, dst, idx_bias=0):
+    """dr_rows_unpack_f32: the wire buffer's segments into dst[idx[e] - idx_bias] (idx None: dst[e])."""
+    dst, k, flat = _wire_args(dst, idx, n, seg_start, seg_off, flat, "dst")
+    check(_abi.lib().dr_rows_unpack_f32(_ptr(flat), flat.numel(), k, _ptr(idx), int(idx_bias), int(n),
+                                        _i64_array(seg_start), _i64_array(seg_off), len(seg_off), _ptr(dst), dst.shape[0],
+                                        _stream()), "dr_rows_unpack_f32")
+
+
 # ------------------------------------------------------------------ row-sharded BPR step (csrc/shard.hip)
 def shard_caps(world, B):
     """Default capacities of a rank: samples it may process / item entries it may own per step.  The mean loads are B

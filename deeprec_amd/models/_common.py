@@ -331,10 +331,15 @@ class TFOptimizer:
 
 class Shard:
     """Placement of row-sharded tables in a data-parallel model: global row r of every table
-    lives on rank r % world at local row r // world; each rank feeds its own slice of the batch."""
+    lives on rank r % world at local row r // world; each rank feeds its own slice of the batch.
+    force: take the sharded path at world 1 as well (every exchange through a size-1 communicator; measurements)."""
 
-    def __init__(self, world=1, rank=0, group=None):
-        self.world, self.rank, self.group = int(world), int(rank), group
+    def __init__(self, world=1, rank=0, group=None, force=False):
+        self.world, self.rank, self.group, self.force = int(world), int(rank), group, bool(force)
+
+    @property
+    def active(self):
+        return self.world > 1 or self.force
 
     def local_rows(self, rows):
         return (rows - self.rank + self.world - 1) // self.world
@@ -343,13 +348,29 @@ class Shard:
         """This rank's rows of a replicated array / tensor."""
         return full[self.rank::self.world]
 
+    def step_route(self, lists):
+        """ONE route for all lookups of a training step (deeprec_amd/sharding.py:StepRoute): 3 collectives, 1 host sync."""
+        from .. import sharding as sh
+        return sh.StepRoute(K, lists, self.world, self.rank, self.group)
+
     def all_reduce_grads(self, params):
-        """Data-parallel dense weights: sum the per-rank gradients (KB-sized; one all-reduce per tensor)."""
-        if self.world > 1:
-            import torch.distributed as dist
-            for p in params:
-                if p.grad is not None:
-                    dist.all_reduce(p.grad, group=self.group)
+        """Data-parallel dense weights: the per-rank gradients summed in ONE all-reduce of their concatenation."""
+        if not self.active:
+            return
+        from .. import sharding as sh
+        gs = [p.grad for p in params if p.grad is not None]
+        if not gs:
+            return
+        flat = torch.cat([g.reshape(-1) for g in gs])
+        sh._all_reduce(flat, self.group)
+        off = 0
+        for g in gs:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+
+def active_shard(shard):
+    return shard if (shard is not None and shard.active) else None
 
 
 class Table:
@@ -369,7 +390,7 @@ class Table:
         self._deferred = []
         self._g = None
         self._hook = torch.zeros((), device=w.device, requires_grad=True)
-        self.shard = shard if (shard is not None and shard.world > 1) else None
+        self.shard = active_shard(shard)
 
     @property
     def w(self):
@@ -471,6 +492,69 @@ class _Lookup(torch.autograd.Function):
             ids = ids.to(torch.int32)
         t.pending.append((ids.contiguous(), gout.reshape(ids.numel(), -1).contiguous() if t.w.dim() == 2
                           else gout.reshape(-1).contiguous()))
+        return None, None, None
+
+
+class _Recorder(list):
+    """pending list of a FetchedRows: tells the route when the first gradient arrives (the order tables record in)."""
+
+    def __init__(self, owner):
+        super().__init__()
+        self.owner = owner
+
+    def append(self, entry):
+        self.owner.route.note(self.owner)
+        super().append(entry)
+
+
+class FetchedRows:
+    """The rows one id list of a StepRoute fetched from a row-sharded Table, presented as a small table that is addressed
+    by POSITION in the list (route.pos(l)): `.w` [n_l, k] (or [n_l]) holds the rows in list order, lookup() and the fused
+    loss kernels work on it as on a Table, and the gradients they record are collected per position and pushed to the
+    owners by route.push()."""
+
+    def __init__(self, table, route, l, rows):
+        self.table, self.route, self.l = table, route, l
+        self._w = self.w = rows
+        self.pending = _Recorder(self)
+        self._hook = table._hook
+        self.shard = None
+
+    @property
+    def k(self):
+        return 1 if self.w.dim() == 1 else self.w.shape[1]
+
+    def _is_identity(self, pos):
+        ident = self.route.pos(self.l)
+        return pos.numel() == ident.numel() and pos.data_ptr() == ident.data_ptr() and pos.is_contiguous()
+
+    def lookup(self, pos):
+        if self._is_identity(pos):
+            return _FetchedAll.apply(self._hook, self, tuple(pos.shape))     # every position in order: no copy
+        return _Lookup.apply(self._hook, self, pos)
+
+    def gradient(self):
+        """d loss / d row per position [n_l, k] (zeros where nothing was recorded)."""
+        ent, n = list(self.pending), self.w.shape[0]
+        del self.pending[:]
+        if len(ent) == 1 and self._is_identity(ent[0][0]):
+            return ent[0][1].reshape(self.w.shape).contiguous()
+        g = torch.zeros_like(self.w)
+        for pos, rows in ent:
+            K.scatter_add(g, pos.reshape(-1).contiguous(), rows.contiguous())
+        return g
+
+
+class _FetchedAll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hook, fr, shape):
+        ctx.fr = fr
+        return fr.w.view(shape + tuple(fr.w.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, gout):
+        fr = ctx.fr
+        fr.pending.append((fr.route.pos(fr.l), gout.reshape(fr.w.shape).contiguous()))
         return None, None, None
 
 
@@ -576,10 +660,11 @@ class _SeqDistLoss(torch.autograd.Function):
     read back from the device, so that the step stays free of host synchronisation and replays as a hipGraph."""
 
     @staticmethod
-    def forward(ctx, o, tP, tX, tQ, users, tgt, neg, alpha, kind, margin):
+    def forward(ctx, o, tP, tX, tQ, users, tgt, neg, alpha, kind, margin, items):
         loss_b, gX, gQ, gp, go = K.seq_dist_loss(tP.w, tX.w, tQ.w, users, o.contiguous(), tgt, neg, alpha, 1.0 - alpha,
                                                  kind, margin)
-        ctx.tabs, ctx.ids = (tP, tX, tQ), (users, torch.cat((tgt, neg), 1).reshape(-1))
+        ctx.tabs = (tP, tX, tQ)
+        ctx.ids = (users, items.reshape(-1) if items is not None else torch.cat((tgt, neg), 1).reshape(-1))
         ctx.save_for_backward(gX, gQ, gp, go)
         return K.sum_f32(loss_b).reshape(())
 
@@ -592,22 +677,24 @@ class _SeqDistLoss(torch.autograd.Function):
         tX.pending.append((items, gX.reshape(-1, k)))
         tQ.pending.append((items, gQ.reshape(-1, k)))
         tP.pending.append((users, gp))
-        return (go,) + (None,) * 9
+        return (go,) + (None,) * 10
 
 
-def seq_dist_loss(o, tP, tX, tQ, users, tgt, neg, alpha, kind, margin=0.5):
+def seq_dist_loss(o, tP, tX, tQ, users, tgt, neg, alpha, kind, margin=0.5, items=None):
     """Scalar loss of the two-distance models; `o` [B, k] is an autograd tensor (attention output / previous-item rows),
-    tP / tX / tQ are Tables whose gradients are recorded like lookup backwards.  Call backward() on the result."""
-    return _SeqDistLoss.apply(o, tP, tX, tQ, users, tgt, neg, float(alpha), int(kind), float(margin))
+    tP / tX / tQ are Tables (or FetchedRows) whose gradients are recorded like lookup backwards.  items: the tensor
+    cat((tgt, neg), 1) when the caller holds it already (the ids the item gradients are recorded under).  Call
+    backward() on the result."""
+    return _SeqDistLoss.apply(o, tP, tX, tQ, users, tgt, neg, float(alpha), int(kind), float(margin), items)
 
 
 class _SeqDotLoss(torch.autograd.Function):
     """Caser's score + mean BCE fused with the W / b lookups (dr_seq_dot_loss_f32); same contract as _SeqDistLoss."""
 
     @staticmethod
-    def forward(ctx, x, tW, tb, tgt, neg, scale):
+    def forward(ctx, x, tW, tb, tgt, neg, scale, items):
         loss_b, gW, gb, gx = K.seq_dot_loss(tW.w, tb.w, x.contiguous(), tgt, neg, scale)
-        ctx.tabs, ctx.items = (tW, tb), torch.cat((tgt, neg), 1).reshape(-1)
+        ctx.tabs, ctx.items = (tW, tb), (items.reshape(-1) if items is not None else torch.cat((tgt, neg), 1).reshape(-1))
         ctx.save_for_backward(gW, gb, gx)
         return K.sum_f32(loss_b).reshape(())
 
@@ -617,11 +704,11 @@ class _SeqDotLoss(torch.autograd.Function):
         tW, tb = ctx.tabs
         tW.pending.append((ctx.items, gW.reshape(-1, gW.shape[2])))
         tb.pending.append((ctx.items, gb.reshape(-1)))
-        return (gx, None, None, None, None, None)
+        return (gx, None, None, None, None, None, None)
 
 
-def seq_dot_loss(x, tW, tb, tgt, neg, scale=1.0):
-    return _SeqDotLoss.apply(x, tW, tb, tgt, neg, float(scale))
+def seq_dot_loss(x, tW, tb, tgt, neg, scale=1.0, items=None):
+    return _SeqDotLoss.apply(x, tW, tb, tgt, neg, float(scale), items)
 
 
 def bi_interaction(table, feats):

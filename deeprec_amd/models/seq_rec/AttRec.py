@@ -13,7 +13,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate1
-from .._common import (GraphedStep, TFOptimizer, Table, attn_seq, seq_dist_loss, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
+from .._common import (GraphedStep, TFOptimizer, Table, active_shard, attn_seq, seq_dist_loss, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 from ._seq_common import SeqBase
 
 
@@ -34,7 +34,7 @@ class AttRec(SeqBase):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.05, reg_rate=1e-2, epoch=5000, batch_size=1000,
                  show_time=False, T=1, display_step=1000, verbose=False, device=None, shard=None, sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
-        self.shard = shard if (shard is not None and shard.world > 1) else None    # _common.Shard: DP over ranks
+        self.shard = active_shard(shard)                    # _common.Shard: data-parallel over ranks, tables row-sharded
         self.learning_rate = learning_rate
         self.epochs = epoch
         self.batch_size = batch_size
@@ -87,9 +87,10 @@ class AttRec(SeqBase):
             self.V.lazy = lazy_v
         return self
 
-    def _seq_out(self, item_seq, want_weights=False):
-        """AttRec.py:142-186 -> (out [B,d], weights [B,L,L] or None)."""
-        v = self.Q.lookup(item_seq)                                     # [B,L,d]
+    def _seq_out(self, item_seq, want_weights=False, Q=None):
+        """AttRec.py:142-186 -> (out [B,d], weights [B,L,L] or None).  Q: the table the sequence rows come from (default
+        self.Q; the fetched rows of a StepRoute in a data-parallel step, item_seq then holds positions)."""
+        v = (Q or self.Q).lookup(item_seq)                              # [B,L,d]
         if self._timing is None:
             self._timing = timing_signal(self.L, self.num_factor, self.device)
         if self.L <= K.ATT_MAX_L and self.num_factor <= K.ATT_MAX_D:
@@ -102,35 +103,56 @@ class AttRec(SeqBase):
         w = torch.softmax(logits, -1) * (1 - eye)
         return (w @ v).mean(1), w
 
-    def _distance(self, out, user_id, item_id, u=None):
+    def _distance(self, out, user_id, item_id, u=None, P=None, X=None, Q=None):
         """AttRec.py:190-232 -> [B, n].  u: the users' P rows when the caller has looked them up already (the train graph
-        uses them for the target and the negative distance: one lookup, one gradient list)."""
-        w_items, w_items_2 = self.X.lookup(item_id), self.Q.lookup(item_id)
-        u = (self.P.lookup(user_id) if u is None else u)[:, None, :]
+        uses them for the target and the negative distance: one lookup, one gradient list).  P, X, Q: row sources other
+        than the model's tables (a data-parallel step's fetched rows)."""
+        w_items, w_items_2 = (X or self.X).lookup(item_id), (Q or self.Q).lookup(item_id)
+        u = ((P or self.P).lookup(user_id) if u is None else u)[:, None, :]
         return self.alpha * ((w_items - u) ** 2).sum(2) + (1 - self.alpha) * ((out[:, None, :] - w_items_2) ** 2).sum(2)
 
     def train_op(self, user_id, item_seq, item_id, neg_item_id):
+        self._zero_dense_grads()
+        loss = self._forward_backward(user_id, item_seq, item_id, neg_item_id)
+        self._apply_step()
+        return loss
+
+    def _zero_dense_grads(self):
         self.linear_project.grad = None
-        out, _ = self._seq_out(item_seq)
-        if (self.shard is None and item_id.shape == neg_item_id.shape and 2 * item_id.shape[1] <= K.SEQ_MAX_SLOTS
-                and not self.unfused):
+
+    def _forward_backward(self, user_id, item_seq, item_id, neg_item_id):
+        """Loss and every gradient of one batch (slice): table gradients are recorded in Table.pending, the projection's
+        accumulates in .grad.  Data-parallel: ONE route for the step's four lookups (sharding.StepRoute: the id
+        all-gather, one exchange of rows, one of gradient rows) and one all-reduce of the dense gradient."""
+        P, X, Q, Qs, items, rt = self.P, self.X, self.Q, self.Q, None, None
+        if self.shard:
+            T_ = item_id.shape[1]
+            rt = self.shard.step_route([item_seq, user_id, torch.cat((item_id, neg_item_id), 1)])
+            Qs, P, X, Q = rt.fetch([(self.Q, 0), (self.P, 1), (self.X, 2), (self.Q, 2)])
+            item_seq, user_id, items = rt.pos(0), rt.pos(1), rt.pos(2)      # positions in the fetched rows
+            item_id, neg_item_id = items[:, :T_].contiguous(), items[:, T_:].contiguous()
+        out, _ = self._seq_out(item_seq, Q=Qs)
+        if item_id.shape == neg_item_id.shape and 2 * item_id.shape[1] <= K.SEQ_MAX_SLOTS and not self.unfused:
             # lookups of P, X, Q rows, both distances, the hinge and every gradient in one kernel (AttRec.py:97,190-232)
-            loss = seq_dist_loss(out, self.P, self.X, self.Q, user_id, item_id, neg_item_id, self.alpha, K.SEQ_LOSS_HINGE, 0.5)
+            loss = seq_dist_loss(out, P, X, Q, user_id, item_id, neg_item_id, self.alpha, K.SEQ_LOSS_HINGE, 0.5, items=items)
         else:
-            u = self.P.lookup(user_id)
-            target = self._distance(out, user_id, item_id, u)
-            negative = self._distance(out, user_id, neg_item_id, u)
+            u = P.lookup(user_id)
+            target = self._distance(out, user_id, item_id, u, P, X, Q)
+            negative = self._distance(out, user_id, neg_item_id, u, P, X, Q)
             loss = torch.clamp(target - negative + 0.5, min=0).sum()
         loss.backward()
-        if self.shard:
+        if rt is not None:
+            rt.push()
             self.shard.all_reduce_grads([self.linear_project])
+        return loss.detach()
+
+    def _apply_step(self):
         o = self.optimizer
         o.begin_step()
         with torch.no_grad():
             for t in (self.P, self.V, self.X, self.Q):
                 o.apply_table(t, 0.001, K.REG_DENSE)
             o.apply_dense(self.linear_project.data, self.linear_project.grad, self.reg_rate)
-        return loss.detach()
 
     def prepare_data(self, train_data, test_data):
         self._prepare(train_data, test_data)

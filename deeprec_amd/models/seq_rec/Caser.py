@@ -14,7 +14,7 @@ import torch
 
 from ... import kernels as K
 from ...utils.evaluation.SeqRecMetrics import evaluate_caser
-from .._common import (TFOptimizer, Table, seq_dot_loss, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
+from .._common import (TFOptimizer, Table, active_shard, seq_dot_loss, device_of, normal_, shift_sess, to_dev, load_checkpoint, save_checkpoint)
 from ._seq_common import SeqBase
 
 
@@ -91,7 +91,7 @@ class Caser(SeqBase):
     def __init__(self, sess, num_user=None, num_item=None, learning_rate=0.001, reg_rate=1e-6, epoch=500, batch_size=1000,
                  show_time=False, T=1, display_step=1000, verbose=False, device=None, shard=None, sampler="reference"):
         self.sess, self.num_user, self.num_item = shift_sess(sess, num_user, num_item)
-        self.shard = shard if (shard is not None and shard.world > 1) else None    # _common.Shard: DP over ranks
+        self.shard = active_shard(shard)                    # _common.Shard: data-parallel over ranks, tables row-sharded
         self.learning_rate = learning_rate
         self.epochs = epoch
         self.batch_size = batch_size
@@ -158,39 +158,65 @@ class Caser(SeqBase):
         self.fc1_dim_v, self.fc1_dim_h = n_v * d, n_h * d
         self.optimizer = TFOptimizer("adam", self.learning_rate, eps=1e-8)
         self.unfused = False        # True: score / BCE as library elementwise ops under autograd
+        self.loss_scale = 1.0       # a caller that feeds 1/n of a batch per call sets 1/n (the loss is a batch MEAN)
         return self
 
     def _dense_params(self):
         return [self.conv_v_w, self.conv_v_b, self.full_w, self.full_b, self.conv_h_wcat, self.conv_h_bcat]
 
-    def _user_emb(self, item_seq, user_id):
-        """Caser.py:98-185 -> x = concat[z, p_u]  [B, 2d]."""
-        e = self.Q.lookup(item_seq)
+    def _user_emb(self, item_seq, user_id, Q=None, P=None):
+        """Caser.py:98-185 -> x = concat[z, p_u]  [B, 2d].  Q, P: row sources other than the model's tables (a
+        data-parallel step's fetched rows; the ids are then positions in them)."""
+        e = (Q or self.Q).lookup(item_seq)
         if self.fused:
             out = caser_convs_fused(e, self.conv_v_w, self.conv_v_b, self.conv_h_wcat, self.conv_h_bcat, self.n_h)
         else:                                   # beyond the kernels' limits (L > 64, d > 256): library ops
             out = caser_convs(e, self.conv_v_w, self.conv_v_b, self.conv_h_w, self.conv_h_b)
         z = torch.relu(out @ self.full_w + self.full_b)
-        return torch.cat((z, self.P.lookup(user_id)), 1)
+        return torch.cat((z, (P or self.P).lookup(user_id)), 1)
 
-    def _score(self, x, item_id):
-        return (x[:, None, :] * self.W.lookup(item_id)).sum(2) + self.b.lookup(item_id)
+    def _score(self, x, item_id, W=None, b=None):
+        return (x[:, None, :] * (W or self.W).lookup(item_id)).sum(2) + (b or self.b).lookup(item_id)
 
     def train_op(self, user_id, item_seq, item_id, neg_item_id):
+        self._zero_dense_grads()
+        loss = self._forward_backward(user_id, item_seq, item_id, neg_item_id)
+        self._apply_step()
+        return loss
+
+    def _zero_dense_grads(self):
         for p in self._dense_params():
             p.grad = None
-        x = self._user_emb(item_seq, user_id)
-        if (self.shard is None and item_id.shape[1] + neg_item_id.shape[1] <= K.SEQ_MAX_SLOTS and not self.unfused):
-            # lookups of W, b rows, the scores, the mean BCE and every gradient in one kernel (Caser.py:79-80,184-192)
-            loss = seq_dot_loss(x, self.W, self.b, item_id, neg_item_id)
-        else:
-            target, negative = self._score(x, item_id), self._score(x, neg_item_id)
-            loss = -torch.log(torch.sigmoid(target) + 1e-10).mean() - torch.log(1 - torch.sigmoid(negative) + 1e-10).mean()
-            if self.shard:
-                loss = loss / self.shard.world      # the loss is a batch MEAN: each rank holds 1/world of the batch
-        loss.backward()
+
+    def _forward_backward(self, user_id, item_seq, item_id, neg_item_id):
+        """Loss and every gradient of one batch (slice): table gradients are recorded in Table.pending, the dense ones
+        accumulate in .grad.  Data-parallel: ONE route for the step's four lookups (sharding.StepRoute: the id all-gather,
+        one exchange of rows, one of gradient rows) and one all-reduce of the dense gradients."""
+        Qs, P, W, b, items, rt = self.Q, self.P, self.W, self.b, None, None
+        scale = self.loss_scale
         if self.shard:
+            T_ = item_id.shape[1]
+            rt = self.shard.step_route([item_seq, user_id, torch.cat((item_id, neg_item_id), 1)])
+            Qs, P, W, b = rt.fetch([(self.Q, 0), (self.P, 1), (self.W, 2), (self.b, 2)])
+            item_seq, user_id, items = rt.pos(0), rt.pos(1), rt.pos(2)      # positions in the fetched rows
+            item_id, neg_item_id = items[:, :T_].contiguous(), items[:, T_:].contiguous()
+            scale = scale / self.shard.world        # the loss is a batch MEAN: each rank holds 1 / world of the batch
+        x = self._user_emb(item_seq, user_id, Qs, P)
+        if item_id.shape[1] + neg_item_id.shape[1] <= K.SEQ_MAX_SLOTS and not self.unfused:
+            # lookups of W, b rows, the scores, the mean BCE and every gradient in one kernel (Caser.py:79-80,184-192)
+            loss = seq_dot_loss(x, W, b, item_id, neg_item_id, scale, items=items)
+        else:
+            target, negative = self._score(x, item_id, W, b), self._score(x, neg_item_id, W, b)
+            loss = -torch.log(torch.sigmoid(target) + 1e-10).mean() - torch.log(1 - torch.sigmoid(negative) + 1e-10).mean()
+            if scale != 1.0:
+                loss = loss * scale
+        loss.backward()
+        if rt is not None:
+            rt.push()
             self.shard.all_reduce_grads(self._dense_params())
+        return loss.detach()
+
+    def _apply_step(self):
         o = self.optimizer
         o.begin_step()
         with torch.no_grad():
@@ -198,7 +224,6 @@ class Caser(SeqBase):
                 o.apply_table(t, self.reg_rate, K.REG_DENSE)
             for p in self._dense_params():
                 o.apply_dense(p.data, p.grad, self.reg_rate if p.dim() > 1 else 0.0)
-        return loss.detach()
 
     def prepare_data(self, train_data, test_data):
         self._prepare(train_data, test_data)

@@ -46,8 +46,13 @@ def _a2a(out, inp, out_splits, in_splits, group, async_op=False):
 
 
 def _gather_ids(out, inp, group):
-    """The id replication: out [W, 3, B] <- every rank's [3, B] (module-level for the same reason as _a2a)."""
+    """The id replication: out [W, ...] <- every rank's [...] (module-level for the same reason as _a2a)."""
     dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=group)
+
+
+def _all_reduce(t, group):
+    """Sum of the data-parallel dense gradients (module-level for the same reason as _a2a)."""
+    dist.all_reduce(t, group=group)
 
 
 class ShardedTable:
@@ -325,6 +330,137 @@ def all_gather_table(T, group=None):
     dist.all_gather(parts, pad, group=group)
     full = torch.stack(parts, 1).reshape(per * T.world, T.k)   # row r = parts[r % W][r // W]
     return full[:T.rows].contiguous()
+
+
+class StepRoute:
+    """ONE route for all lookups of a data-parallel training step (AttRec.py:142,190-193,205,215; Caser.py:61-64,165-166;
+    SURVEY 8e config 5): the step's id lists (item sequence, users, targets | negatives ...; GLOBAL row numbers, the same
+    shapes on every rank) are replicated with one all-gather, both roles of this rank are derived locally
+    (dr_step_route_keys_i32 + two stable bucketings: what it asks of each owner, in which order; what each peer asks of
+    it), the counts reach the host in ONE synchronisation, and then
+
+        fetch([(table, list), ...])   ONE all-to-all brings the rows of every (table, list) pair
+        push()                        ONE all-to-all takes every gradient row back to the owner of its row,
+
+    where they are recorded for TFOptimizer.apply_table like a local lookup's, in the order a single process sees for
+    the concatenated global batch (list by list, source rank by source rank, each source's in the order of its list):
+    the tables of a world-W run are bit-identical to those of one process that runs the same W batch slices.
+    Three collectives and one host synchronisation per step, whatever the number of tables (the per-lookup RowRoute
+    below: a count exchange, a host synchronisation and three all-to-alls per lookup).  Rows of different widths share
+    the wire: a peer's block holds one 16-byte-aligned segment per (table, list) pair (csrc/wire.hip)."""
+
+    def __init__(self, ops, lists, world, rank, group=None):
+        self.ops, self.world, self.rank, self.group = ops, int(world), int(rank), group
+        W, nl = self.world, len(lists)
+        flat = [t.reshape(-1) if t.dtype == torch.int32 else t.reshape(-1).to(torch.int32) for t in lists]
+        self.shapes = [tuple(t.shape) for t in lists]
+        self.n = [t.numel() for t in flat]
+        self.start = [0]
+        for c in self.n:
+            self.start.append(self.start[-1] + c)
+        n_tot = self.start[-1]
+        mine = (torch.cat(flat) if nl > 1 else flat[0]).contiguous()
+        dev = mine.device
+        ids_all = torch.empty((W, n_tot), dtype=torch.int32, device=dev)
+        _gather_ids(ids_all, mine, group)                                   # collective 1 of 3
+        km, ko, loc = ops.step_route_keys(ids_all, self.rank, self.start)
+        order_m, cnt_m = ops.bucket_order(km, nl * W)                       # my entries by (list, owner)
+        order_o, cnt_o = ops.bucket_order(ko, nl * W)                       # entries I own by (list, source rank)
+        c = torch.cat((cnt_m[:nl * W], cnt_o[:nl * W])).tolist()            # the ONE host synchronisation of a step
+        self.send_cnt = [c[l * W:(l + 1) * W] for l in range(nl)]           # [list][owner]: rows I ask of each owner
+        self.recv_cnt = [c[(nl + l) * W:(nl + l + 1) * W] for l in range(nl)]   # [list][source]: rows each peer asks of me
+        self.n_own = [sum(r) for r in self.recv_cnt]
+        # my entries of list l in wire order (by owner, then list position): positions in `mine`, bias start[l]
+        self.send_idx = [order_m[self.start[l]:self.start[l + 1]] for l in range(nl)]
+        # local rows the peers ask of me, by source rank, each source's in its list order
+        self.want, off = [], 0
+        for l in range(nl):
+            self.want.append(torch.index_select(loc, 0, order_o[off:off + self.n_own[l]]))
+            off += self.n_own[l]
+        self._pos = [None] * nl
+        self._specs, self._fetched, self._order = None, [], []
+
+    def pos(self, l):
+        """Positions 0 .. n_l - 1 in the shape of list l: what a lookup in the fetched rows is addressed with."""
+        if self._pos[l] is None:
+            self._pos[l] = torch.arange(self.n[l], dtype=torch.int32, device=self.want[l].device).reshape(self.shapes[l])
+        return self._pos[l]
+
+    @staticmethod
+    def _prefix(counts):
+        out = [0]
+        for c in counts:
+            out.append(out[-1] + c)
+        return out
+
+    def _layout(self, specs):
+        """Wire layout of the pairs `specs` = [(k, list)]: per peer one block, inside it one segment per pair, padded to
+        4 floats.  `out`: blocks I send as an owner (rows the peers asked for); `in`: blocks I receive."""
+        W = self.world
+        pad = lambda x: (x + 3) // 4 * 4
+        ob, ib = [0] * W, [0] * W
+        ow, iw = [], []
+        for k, l in specs:
+            ow.append(list(ob))
+            iw.append(list(ib))
+            for p in range(W):
+                ob[p] += pad(self.recv_cnt[l][p] * k)
+                ib[p] += pad(self.send_cnt[l][p] * k)
+        obase, ibase = self._prefix(ob), self._prefix(ib)
+        self.out_split, self.in_split = ob, ib
+        self.out_off = [[obase[p] + w[p] for p in range(W)] for w in ow]
+        self.in_off = [[ibase[p] + w[p] for p in range(W)] for w in iw]
+
+    def fetch(self, pairs):
+        """pairs = [(Table, list index)]: ONE exchange; returns a FetchedRows per pair (rows in the order of the list)."""
+        from .models._common import FetchedRows
+        ops = self.ops
+        if self._specs is not None:
+            raise RuntimeError("StepRoute.fetch: one fetch per route (list every (table, list) pair in it)")
+        self._specs = [(t.k, l) for t, l in pairs]
+        self._layout(self._specs)
+        dev = self.want[0].device
+        send = torch.empty(sum(self.out_split), dtype=torch.float32, device=dev)
+        recv = torch.empty(sum(self.in_split), dtype=torch.float32, device=dev)
+        for f, (t, l) in enumerate(pairs):                                  # the owner's gather, straight into the wire
+            ops.rows_pack(t.w, self.want[l], self.n_own[l], self._prefix(self.recv_cnt[l]), self.out_off[f], send)
+        _a2a(recv, send, self.in_split, self.out_split, self.group)         # collective 2 of 3
+        for f, (t, l) in enumerate(pairs):
+            rows = torch.empty((self.n[l],) + tuple(t.w.shape[1:]), dtype=torch.float32, device=dev)
+            ops.rows_unpack(recv, self.send_idx[l], self.n[l], self._prefix(self.send_cnt[l]), self.in_off[f], rows,
+                            idx_bias=self.start[l])
+            self._fetched.append(FetchedRows(t, self, l, rows))
+        return list(self._fetched)
+
+    def note(self, fetched):
+        """A FetchedRows received its first gradient: tables record the pushed rows in this order (the order a single
+        process's autograd appends them in)."""
+        if fetched not in self._order:
+            self._order.append(fetched)
+
+    def push(self):
+        """ONE exchange takes the gradient rows every fetched pair collected to the owners, where they are appended to
+        Table.pending (ids = local rows, in global batch order)."""
+        ops = self.ops
+        if not self._order:
+            return
+        dev = self.want[0].device
+        send = torch.empty(sum(self.in_split), dtype=torch.float32, device=dev)
+        recv = torch.empty(sum(self.out_split), dtype=torch.float32, device=dev)
+        for f, fr in enumerate(self._fetched):
+            l = fr.l
+            ops.rows_pack(fr.gradient(), self.send_idx[l], self.n[l], self._prefix(self.send_cnt[l]), self.in_off[f],
+                          send, idx_bias=self.start[l])
+        _a2a(recv, send, self.out_split, self.in_split, self.group)         # collective 3 of 3
+        got = {}
+        for f, fr in enumerate(self._fetched):
+            l = fr.l
+            rows = torch.empty((self.n_own[l],) + tuple(fr.w.shape[1:]), dtype=torch.float32, device=dev)
+            ops.rows_unpack(recv, None, self.n_own[l], self._prefix(self.recv_cnt[l]), self.out_off[f], rows)
+            got[id(fr)] = rows
+        for fr in self._order:
+            fr.table.pending.append((self.want[fr.l], got[id(fr)]))
+        self._order = []
 
 
 class RowRoute:

@@ -356,6 +356,33 @@ int64_t dr_bucket_order_bytes(int64_t n);
 int32_t dr_bucket_order_i32(const int32_t* keys, int64_t n, int32_t nkeys, int32_t* order, int64_t* counts, void* ws,
                             int64_t ws_bytes, void* stream);
 
+/* ---- one route per training step of a data-parallel model (no counterpart in the reference) ----
+ * The lookups of one AttRec / Caser step (AttRec.py:142,190-193,205,215; Caser.py:61-64,165-166) read several tables
+ * through a few id lists (item sequence, users, targets | negatives).  Every rank all-gathers its concatenated lists
+ * (ids_all [world, n_tot], list l = entries list_start[l] .. list_start[l+1] of each rank's part) and derives BOTH roles
+ * locally: for entry x = s * n_tot + p (rank s, position p, list l), owner = id mod world, local_rows[x] = floor(id /
+ * world); keys_mine[p] = l * world + owner for this rank's own entries (a stable bucketing gives the order its rows
+ * travel in, per owner); keys_owned[x] = l * world + s where this rank owns the row, else n_lists * world (the
+ * bucketing's overflow bucket) -- a stable bucketing lists, per list and source rank, the rows it serves, in the order
+ * a single process sees for the concatenated global batch.  n_lists <= DR_ROUTE_MAX_LISTS, n_lists * world <= 256. */
+#define DR_ROUTE_MAX_LISTS 16
+int32_t dr_step_route_keys_i32(const int32_t* ids_all, int32_t world, int32_t me, int64_t n_tot,
+                               const int64_t* list_start, int32_t n_lists, int32_t* keys_mine, int32_t* keys_owned,
+                               int32_t* local_rows, void* stream);
+/* Wire buffers of that route: all tables' rows travel in ONE all-to-all (and all gradient rows in one back).  `flat` is
+ * a float array; entries e in [seg_start[s], seg_start[s+1]) form segment s (HOST arrays, nseg <= DR_WIRE_MAX_SEG,
+ * seg_start[0] = 0, seg_start[nseg] = n), whose rows lie contiguously from flat + seg_off[s] (floats; a multiple of 4,
+ * 2 or 1 as k is).  pack: flat row of entry e = src[idx[e] - idx_bias] (idx NULL: src[e]; a row outside [0, src_rows)
+ * packs zeros, like dr_gather_f32).  unpack: dst[idx[e] - idx_bias] = flat row of entry e (idx NULL: dst[e]; rows
+ * outside [0, dst_rows) are skipped; idx must not repeat a row). */
+#define DR_WIRE_MAX_SEG 64
+int32_t dr_rows_pack_f32(const float* src, int64_t src_rows, int32_t k, const int32_t* idx, int32_t idx_bias,
+                         int64_t n, const int64_t* seg_start, const int64_t* seg_off, int32_t nseg, float* flat,
+                         int64_t flat_floats, void* stream);
+int32_t dr_rows_unpack_f32(const float* flat, int64_t flat_floats, int32_t k, const int32_t* idx, int32_t idx_bias,
+                           int64_t n, const int64_t* seg_start, const int64_t* seg_off, int32_t nseg, float* dst,
+                           int64_t dst_rows, void* stream);
+
 /* ---- small dense towers behind the embeddings -------------------------------------------
  * h_0 = x [B, dims[0]];  h_{l+1} = act_l(h_l W_l + b_l), W_l [dims[l], dims[l+1]] row-major, l = 0 .. L-1 (L <= 8, every
  * width <= 256).  Replaces the tf.layers.dense chains of neumf.py:80-113, nnmf.py:60-80 and nfm.py:64-69: one kernel for

@@ -21,7 +21,50 @@ def gather(table, ids, oob="zero"):
 def bucket_order(keys, nkeys):
     kk = _n(keys).astype(np.int64)
     order = np.argsort(kk, kind="stable").astype(np.int32)
-    return torch.from_numpy(order), torch.from_numpy(np.bincount(kk, minlength=nkeys).astype(np.int64))
+    return torch.from_numpy(order), torch.from_numpy(np.bincount(kk, minlength=nkeys)[:nkeys].astype(np.int64))
+
+
+def step_route_keys(ids_all, me, list_start):
+    """dr_step_route_keys_i32 (include/deeprec_amd.h) restated with numpy."""
+    g = _n(ids_all).astype(np.int64)
+    W, n_tot = g.shape
+    nl = len(list_start) - 1
+    lst = np.searchsorted(np.asarray(list_start[1:], np.int64), np.arange(n_tot), side="right")
+    owner = g % W
+    src = np.repeat(np.arange(W), n_tot).reshape(W, n_tot)
+    ko = np.where(owner == me, lst[None, :] * W + src, nl * W)
+    km = lst * W + owner[me]
+    return (torch.from_numpy(km.astype(np.int32)), torch.from_numpy(ko.reshape(-1).astype(np.int32)),
+            torch.from_numpy((g // W).reshape(-1).astype(np.int32)))
+
+
+def _wire_rows(n, k, seg_start, seg_off):
+    """Float offset of every entry's row in the wire buffer."""
+    e = np.arange(n)
+    s = np.searchsorted(np.asarray(seg_start[1:], np.int64), e, side="right")
+    return np.asarray(seg_off, np.int64)[s] + (e - np.asarray(seg_start, np.int64)[s]) * k
+
+
+def rows_pack(src, idx, n, seg_start, seg_off, flat, idx_bias=0):
+    sn = _n(src).reshape(src.shape[0], -1)
+    k = sn.shape[1]
+    r = np.arange(n) if idx is None else _n(idx).astype(np.int64) - idx_bias
+    rows = np.zeros((n, k), np.float32)
+    ok = (r >= 0) & (r < sn.shape[0])
+    rows[ok] = sn[r[ok]]
+    out = _n(flat)
+    for e, w in enumerate(_wire_rows(n, k, seg_start, seg_off)):
+        out[w:w + k] = rows[e]
+
+
+def rows_unpack(flat, idx, n, seg_start, seg_off, dst, idx_bias=0):
+    dn = _n(dst).reshape(dst.shape[0], -1)
+    k = dn.shape[1]
+    r = np.arange(n) if idx is None else _n(idx).astype(np.int64) - idx_bias
+    fl = _n(flat)
+    for e, w in enumerate(_wire_rows(n, k, seg_start, seg_off)):
+        if 0 <= r[e] < dn.shape[0]:
+            dn[r[e]] = fl[w:w + k]
 
 
 def shard_caps(world, B):

@@ -243,8 +243,14 @@ def _stage_through_host(sh, dist):
         dist.all_gather_into_tensor(oc.view(-1), inp.cpu().view(-1), group=group)
         o.copy_(oc)
 
+    def reduce_staged(t, group):
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+
     sh._a2a = staged
     sh._gather_ids = gather_staged
+    sh._all_reduce = reduce_staged
 
 
 def _worker2(rank, world, port, out):
@@ -462,15 +468,22 @@ def _seq_worker(rank, world, port, cls_name, out):
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         _stage_through_host(sh, dist)
-        shard = Shard(world, rank)
-        # dense gradients are all-reduced on the device: stage them through the host as well (gloo)
-        shard.all_reduce_grads = lambda params: [p.grad.copy_(_allreduce_host(dist, p.grad)) for p in params if p.grad is not None]
-        m, steps = _seq_model(cls_name, dev, shard)
+        # count what one step costs: collectives (the staged exchange functions) and host synchronisations of the route
+        calls = {"collectives": 0}
+        for name in ("_a2a", "_gather_ids", "_all_reduce"):
+            def counted(*a, _f=getattr(sh, name), **kw):
+                calls["collectives"] += 1
+                return _f(*a, **kw)
+            setattr(sh, name, counted)
+        m, steps = _seq_model(cls_name, dev, Shard(world, rank))
         per = len(steps[0][0]) // world
         losses = []
         for b in steps:
             mine = tuple(T(x[rank * per:(rank + 1) * per], dev) for x in b)
+            calls["collectives"] = 0
             l = m.train_op(*mine).cpu()
+            # id all-gather + rows in + gradient rows out + ONE all-reduce of the dense gradients, for 4 lookups in 4 tables
+            assert calls["collectives"] == 4, calls
             dist.all_reduce(l)
             losses.append(float(l))
         res = {}
@@ -484,9 +497,7 @@ def _seq_worker(rank, world, port, cls_name, out):
             parts = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(parts, pad)
             res[n] = torch.stack(parts, 1).reshape((per_r * world,) + tuple(w.shape[1:]))[:rows].numpy()
-        dense = {"linear_project": m.linear_project} if cls_name == "AttRec" else {"full_w": m.full_w, "conv_v_w": m.conv_v_w,
-                                                                                  "conv_h_w3": m.conv_h_w[2]}
-        for n, p in dense.items():
+        for n, p in _seq_dense(cls_name, m).items():
             res[n] = p.detach().cpu().numpy()
         if rank == 0:
             np.savez(out, losses=np.array(losses), **res)
@@ -494,29 +505,143 @@ def _seq_worker(rank, world, port, cls_name, out):
         dist.destroy_process_group()
 
 
-def _allreduce_host(dist, g):
-    c = g.cpu()
-    dist.all_reduce(c)
-    return c.to(g.device)
+def _seq_dense(cls_name, m):
+    if cls_name == "AttRec":
+        return {"linear_project": m.linear_project}
+    return {"full_w": m.full_w, "full_b": m.full_b, "conv_v_w": m.conv_v_w, "conv_v_b": m.conv_v_b,
+            "conv_h_wcat": m.conv_h_wcat, "conv_h_bcat": m.conv_h_bcat}
+
+
+def _sliced_step(m, batch, world, dev):
+    """What `world` data-parallel ranks compute, run by ONE process on unsharded tables: forward + backward slice by
+    slice (the dense layers see the per-rank shapes, the dense gradients accumulate slice 0 + slice 1 like the all-reduce
+    of two ranks), the recorded table gradients regrouped lookup by lookup with the slices in rank order -- the order a
+    single process sees for the concatenated batch -- and one optimizer application."""
+    from deeprec_amd.models._common import Table
+    per = len(batch[0]) // world
+    m._zero_dense_grads()
+    m.loss_scale = 1.0 / world                                  # Caser's loss is a batch mean (AttRec's a sum: unused)
+    loss = 0.0
+    for r in range(world):
+        loss += float(m._forward_backward(*(T(x[r * per:(r + 1) * per], dev) for x in batch)))
+    for t in vars(m).values():
+        if isinstance(t, Table) and t.pending:
+            nl = len(t.pending) // world
+            t.pending = [(torch.cat([t.pending[r * nl + j][0] for r in range(world)]),
+                          torch.cat([t.pending[r * nl + j][1] for r in range(world)])) for j in range(nl)]
+    m._apply_step()
+    return loss
 
 
 @pytest.mark.parametrize("cls_name", ["AttRec", "Caser"])
 def test_data_parallel_seq_models_equal_single_gpu(dev, tmp_path, cls_name):
-    """BASELINE config 5: the batch split over 2 ranks (sharing the box's GPU), every table row-sharded (lookups fetch
-    rows from their owners, gradient rows go back and are applied in global batch order), the small dense weights
-    all-reduced: after 3 steps tables and dense weights equal the single-GPU model's on the whole batch (fp32
-    tolerance: the dense layers see other GEMM shapes per rank)."""
+    """BASELINE config 5: the batch split over 2 ranks (sharing the box's GPU), every table row-sharded, ONE route per
+    step (sharding.StepRoute: 3 collectives + the dense all-reduce, asserted in the workers), gradient rows applied in
+    global batch order.  After 3 steps
+    (a) tables AND dense weights are BIT-IDENTICAL to one process that runs the same two batch slices through the same
+        kernels (_sliced_step) -- the exchange adds, drops and reorders nothing;
+    (b) against the single-GPU model fed the whole batch at once they agree to fp32 tolerance only (2e-4 relative):
+        the dense layers (projection / convolutions / FC, library GEMMs and batch reductions) see other shapes per
+        rank and sum the batch in another order, which no exchange can undo."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "seq.npz")
     mp.spawn(_seq_worker, args=(2, _free_port(), cls_name, out), nprocs=2, join=True)
     res = np.load(out)
+    tables = [n for n in ("P", "V", "Q", "X", "W", "b")]
+    # (a) bit for bit
+    m, steps = _seq_model(cls_name, dev)
+    losses = [_sliced_step(m, b, 2, dev) for b in steps]
+    np.testing.assert_allclose(res["losses"], losses, rtol=1e-6)
+    for n in tables:
+        if hasattr(m, n):
+            _same(res[n], N(getattr(m, n).w), cls_name + "." + n)
+    for n, p in _seq_dense(cls_name, m).items():
+        _same(res[n], N(p), cls_name + "." + n)
+    # (b) the whole batch at once
     m, steps = _seq_model(cls_name, dev)
     losses = [float(m.train_op(*(T(x, dev) for x in b))) for b in steps]
     np.testing.assert_allclose(res["losses"], losses, rtol=2e-5)
-    for n in ("P", "V", "Q", "X", "W", "b"):
+    for n in tables:
         if hasattr(m, n):
             np.testing.assert_allclose(res[n], N(getattr(m, n).w), rtol=2e-4, atol=2e-6, err_msg=n)
-    dense = {"linear_project": m.linear_project} if cls_name == "AttRec" else {"full_w": m.full_w, "conv_v_w": m.conv_v_w,
-                                                                              "conv_h_w3": m.conv_h_w[2]}
-    for n, p in dense.items():
+    for n, p in _seq_dense(cls_name, m).items():
         np.testing.assert_allclose(res[n], N(p), rtol=2e-4, atol=2e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("cls_name", ["AttRec", "Caser"])
+def test_seq_models_world1_through_rccl_equal_unsharded(dev, cls_name):
+    """Shard(world 1, force=True): the one-route step with every exchange through RCCL (size-1 communicator) is
+    bit-identical to the plain single-GPU step (same kernels on the same rows in the same order)."""
+    import torch.distributed as dist
+    from deeprec_amd.models._common import Shard
+    m0, steps = _seq_model(cls_name, dev)
+    want = [float(m0.train_op(*(T(x, dev) for x in b))) for b in steps]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        m1, _ = _seq_model(cls_name, dev, Shard(1, 0, force=True))
+        assert m1.shard is not None and m1.Q.shard is not None
+        got = [float(m1.train_op(*(T(x, dev) for x in b))) for b in steps]
+    finally:
+        dist.destroy_process_group()
+    assert got == want
+    for n in ("P", "V", "Q", "X", "W", "b"):
+        if hasattr(m0, n):
+            _same(N(getattr(m1, n).w), N(getattr(m0, n).w), cls_name + "." + n)
+    for (n, a), b in zip(_seq_dense(cls_name, m1).items(), _seq_dense(cls_name, m0).values()):
+        _same(N(a), N(b), cls_name + "." + n)
+
+
+# ------------------------------------------------------------------ the route's kernels vs their numpy restatement
+@pytest.mark.parametrize("W,sizes", [(1, [5]), (2, [64 * 6, 64, 128]), (3, [1, 0, 7]), (8, [4096 * 50, 4096, 4096 * 6]),
+                                     (16, [1000] * 16)])
+def test_step_route_keys_and_wire_kernels(dev, W, sizes):
+    """dr_step_route_keys_i32, dr_rows_pack_f32 and dr_rows_unpack_f32 against tests/_oracle_ops.py, bit for bit, for
+    every rank of the world; rows of width 1 (a bias vector), 6, 128 and 150 share one wire buffer."""
+    from deeprec_amd import kernels as K
+    import _oracle_ops as O
+    rng = np.random.default_rng(W + len(sizes))
+    start = np.concatenate(([0], np.cumsum(sizes))).tolist()
+    n_tot = start[-1]
+    ids = rng.integers(-3, 100000, (W, n_tot)).astype(np.int32)
+    for me in sorted({0, W // 2, W - 1}):
+        got = K.step_route_keys(T(ids, dev), me, start)
+        want = O.step_route_keys(torch.from_numpy(ids), me, start)
+        for g, w, nm in zip(got, want, ("keys_mine", "keys_owned", "local_rows")):
+            assert np.array_equal(N(g), w.numpy()), (me, nm)
+    # wire: segments of different row widths interleaved per peer, padded to 4 floats
+    n = min(n_tot, 3000)
+    if n == 0:
+        return
+    for k in (1, 6, 128, 150):
+        cuts = np.sort(rng.integers(0, n + 1, W - 1)) if W > 1 else np.zeros(0, np.int64)
+        seg_start = [0] + [int(c) for c in cuts] + [n]
+        seg_off, off = [], 8
+        for s_ in range(W):
+            seg_off.append(off)
+            off += ((seg_start[s_ + 1] - seg_start[s_]) * k + 3) // 4 * 4 + 4 * int(rng.integers(0, 3))
+        rows = 2 * n + 5
+        src = rng.standard_normal((rows, k) if k > 1 else rows).astype(np.float32)
+        idx = (rng.integers(-2, rows + 2, n) + 7).astype(np.int32)
+        flat_g = torch.full((off,), -1.0, device=dev)
+        flat_o = torch.full((off,), -1.0)
+        K.rows_pack(T(src, dev), T(idx, dev), n, seg_start, seg_off, flat_g, idx_bias=7)
+        O.rows_pack(torch.from_numpy(src), torch.from_numpy(idx), n, seg_start, seg_off, flat_o, idx_bias=7)
+        _same(N(flat_g), flat_o.numpy(), ("pack", k))
+        K.rows_pack(T(src, dev), None, n, seg_start, seg_off, flat_g)
+        O.rows_pack(torch.from_numpy(src), None, n, seg_start, seg_off, flat_o)
+        _same(N(flat_g), flat_o.numpy(), ("pack, no index", k))
+        perm = (rng.permutation(rows)[:n] + 7).astype(np.int32)
+        perm[0] = 3                                                 # below the bias: skipped
+        dst_g = torch.full(src.shape, -2.0, device=dev)
+        dst_o = torch.full(src.shape, -2.0)
+        K.rows_unpack(flat_g, T(perm, dev), n, seg_start, seg_off, dst_g, idx_bias=7)
+        O.rows_unpack(flat_o, torch.from_numpy(perm), n, seg_start, seg_off, dst_o, idx_bias=7)
+        _same(N(dst_g), dst_o.numpy(), ("unpack", k))
+        K.rows_unpack(flat_g, None, n, seg_start, seg_off, dst_g)
+        O.rows_unpack(flat_o, None, n, seg_start, seg_off, dst_o)
+        _same(N(dst_g), dst_o.numpy(), ("unpack, no index", k))
+    with pytest.raises(Exception):
+        K.rows_pack(T(src, dev), None, n, seg_start, [o + 1 for o in seg_off], flat_g)      # misaligned segment
+    with pytest.raises(Exception):
+        K.rows_pack(T(src, dev), None, n, seg_start, [off] * W, flat_g)                     # past the buffer

@@ -260,3 +260,75 @@ def test_sharded_step_ranks_without_work_and_bad_ids(tmp_path):
     assert np.array_equal(res["Q"].view(np.uint32), Q1.view(np.uint32))
     np.testing.assert_allclose(float(res["loss"]), loss, rtol=1e-6)
     assert list(res["flags"]) == [True, True, True]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one route per training step of the data-parallel sequence models (sharding.StepRoute)
+# ---------------------------------------------------------------------------------------------------------------
+def _route_case(seed, world):
+    rng = np.random.default_rng(seed)
+    R1, R2, k1, k2 = 53, 31, 6, 10
+    T1 = rng.standard_normal((R1, k1)).astype(np.float32)
+    T2 = rng.standard_normal((R2, k2)).astype(np.float32)
+    bv = rng.standard_normal(R2).astype(np.float32)
+    lists = [((rng.zipf(1.3, (7, 3)) % R1).astype(np.int32), rng.integers(0, R2, 9).astype(np.int32)) for _ in range(world)]
+    lists[0][1][2] = R2 + 5                                     # a row nobody has: fetched as zeros, its gradient dropped
+    grads = [[rng.standard_normal((21, k1)).astype(np.float32), rng.standard_normal((9, k2)).astype(np.float32),
+              rng.standard_normal(9).astype(np.float32)] for _ in range(world)]
+    return T1, T2, bv, lists, grads
+
+
+def _route_worker(rank, world, port, seed, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import _oracle_ops as ops
+        from deeprec_amd import sharding as sh
+        from deeprec_amd.models._common import Shard, Table
+        T1, T2, bv, lists, grads = _route_case(seed, world)
+        shd = Shard(world, rank)
+        tabs = [Table(torch.from_numpy(np.ascontiguousarray(a[rank::world])), shd) for a in (T1, T2, bv)]
+        rt = sh.StepRoute(ops, [torch.from_numpy(x) for x in lists[rank]], world, rank)
+        fr = rt.fetch([(tabs[0], 0), (tabs[1], 1), (tabs[2], 1)])
+        # gradients arrive in the order a backward pass would record them: pair 2 first, then 0, then 1
+        for f in (2, 0, 1):
+            fr[f].pending.append((rt.pos(fr[f].l), torch.from_numpy(grads[rank][f])))
+        rt.push()
+        res = {"rows%d" % f: fr[f].w.numpy() for f in range(3)}
+        for t, name in zip(tabs, ("T1", "T2", "b")):
+            assert len(t.pending) == 1
+            res["ids_" + name], res["g_" + name] = t.pending[0][0].numpy(), t.pending[0][1].numpy()
+        np.savez(out % rank, **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_step_route_fetches_and_pushes_in_global_batch_order(tmp_path, world):
+    """sharding.StepRoute over gloo: every (table, list) pair's rows in one exchange == a lookup in the full table;
+    the pushed gradient rows arrive at the owner of each row list by list, source rank by source rank, each source's in
+    list order -- what a single process records for the concatenated global batch."""
+    seed = 21
+    out = str(tmp_path / "route%d.npz")
+    if world == 1:
+        _route_worker(0, 1, _free_port(), seed, out)
+    else:
+        mp.spawn(_route_worker, args=(world, _free_port(), seed, out), nprocs=world, join=True)
+    T1, T2, bv, lists, grads = _route_case(seed, world)
+    full = (T1, T2, bv)
+    for r in range(world):
+        res = np.load(out % r)
+        for f, (tab, l) in enumerate(((T1, 0), (T2, 1), (bv, 1))):
+            ids = lists[r][l].reshape(-1)
+            ok = ids < tab.shape[0]
+            want = np.zeros((len(ids),) + tab.shape[1:], np.float32)
+            want[ok] = tab[ids[ok]]
+            assert np.array_equal(res["rows%d" % f], want), (r, f)
+        for name, f, l in (("T1", 0, 0), ("T2", 1, 1), ("b", 2, 1)):
+            ids = np.concatenate([lists[s][l].reshape(-1) for s in range(world)])
+            g = np.concatenate([grads[s][f] for s in range(world)])
+            mine = ids % world == r
+            assert np.array_equal(res["ids_" + name], ids[mine] // world), (r, name)
+            assert np.array_equal(res["g_" + name], g[mine]), (r, name)
