@@ -604,6 +604,18 @@ __global__ __launch_bounds__(256) void hconv_bwd_filter_kernel(const float* __re
 // 1.9 ms at C5: per useful FMA the (g, t0) look-ups, address arithmetic and selects cost more vector instructions than
 // the per-(height, filter) workgroups above spend, and 8 waves per CU hide less latency than their 32.)
 
+// (Round 3, tried and removed -- tools/hconv_bwd_probe.py at C5, rocprofv3: d e 2.31 ms, d W 1.87 ms for the two kernels above.
+//  (a) "Second form": a thread owns ONE output row over a 32-column slice with its 32 sums in registers -- position p of
+//  sequence s for d e (lanes = positions, 96 filter rows per double-buffered LDS stage shared by 10 sequences), row r of
+//  filter (h, c) for d W (lanes = filter rows, 2 sequences per stage) -- and per contribution reads the other operand's
+//  row slice with eight ds_read_b128 and does 16 v_pk_fma_f32.  Bit-identical, 3.5x fewer vector instructions per FMA, but
+//  d e 2.69 ms and d W 2.11-2.21 ms (3.8 ms when cut to 96 VGPRs: spills): every contribution's 128-byte slice crosses the
+//  LDS once per LANE (43 GB per kernel, 0.55 ms at 128 B/clk/CU if every lane were useful); with lanes = positions only
+//  h / L of them are covered (SQ_ACTIVE_INST_LDS 73 % of SQ_BUSY_CYCLES), with lanes = filter rows the 16-lane groups of
+//  ds_read_b128 straddle filters with unrelated winners (SQ_LDS_BANK_CONFLICT = SQ_ACTIVE_INST_LDS: 2-way on average).
+//  (b) The kernels above with the next filter's rows (d e) / two or four sequences' rows (d W) requested before the current
+//  FMAs: 3.87 / 3.04 ms (4.37 with four) -- the extra registers cost more occupancy than the overlap returns.
+//  A dense MFMA form does L times the useful products (one winner among L - h + 1 positions), i.e. the forward's 3.2 ms.)
 // ---- vertical convolution (Caser.py:118-130): out[b, col * n_v + v] = bias[v] + sum_l w[v, l] e[b, l, col] -------------
 // One thread per (sequence, column): the L slab elements of its column are read once (coalesced over the columns), the
 // n_v filters sit in LDS.  HBM / L2 bound on the slab (B L d floats); no MFMA: n_v = 4 outputs per L = 50 inputs.

@@ -4,7 +4,7 @@
 cases, not bench lines: this tool only records where each one stands (synthetic ids of the right shape, random
 weights; one JSON object on stdout, kept under profiles/).
 
-    python tools/bench_configs.py > profiles/r02_configs.json
+    python tools/bench_configs.py profiles/r03_configs.json
 """
 import contextlib
 import io
@@ -151,6 +151,21 @@ def main():
                                        "table the graph never reads) is recorded and replayed when V is read"}
         del m
         torch.cuda.empty_cache()
+        # data-parallel form at world 1: every table row-sharded (one shard), ONE route per step (sharding.StepRoute: id
+        # all-gather, rows in, gradient rows out, dense all-reduce -- all four through a size-1 RCCL communicator)
+        import torch.distributed as dist
+        from deeprec_amd.models._common import Shard
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        m = quiet(cls, None, nu, ni, 0.05 if cls is AttRec else 0.001, 0.01, 1, B, shard=Shard(1, 0, force=True))
+        quiet(m.build_network, L, T_, **kw)
+        ms_sh = timed(lambda: m.train_op(*bs[next(it) % 4]), 20, 3)
+        out["C5_%s" % name]["ms_per_step_sharded_world1_rccl"] = ms_sh
+        out["C5_%s" % name]["sharded_step"] = "3 collectives (ids, rows in, gradient rows out) + 1 all-reduce, 1 host sync"
+        del m
+        torch.cuda.empty_cache()
     say("   C5 eval")
     # ---- C5 evaluation (SeqRecMetrics.evaluate1 / evaluate_caser): all items for a block of users, rank of one held-out
     # item (what HR@50 / MRR / AUC need; the evaluators keep no top-K list: K = 1), 50 masked train items per user; AttRec's two-distance score and Caser's dot + item bias
@@ -175,7 +190,13 @@ def main():
     out["C5_Caser"]["eval_ms_65536_users_x_100k_items"] = ms
     out["C5_Caser"]["eval_users_per_s"] = Nu / ms * 1e3
     out["C5_Caser"]["eval_TFLOPs"] = fl / ms / 1e9
+    if len(sys.argv) > 1:           # RCCL prints its version banner on stdout: give a path to get a clean file
+        with open(sys.argv[1], "w") as f:
+            json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 main()
