@@ -613,6 +613,11 @@ def extras(args, K, P, Q, sP, sQ, batches, opt_for, stream, device, ms_per_step,
     flops = 2.0 * Nu * args.items * k
     out["eval"] = {"users": Nu, "items": args.items, "K": 10, "avg_ms": t_ev, "users_per_s": Nu / (t_ev * 1e-3),
                    "TFLOPs": flops / (t_ev * 1e-3) / 1e12, "frac_mfma_f32_peak": flops / (t_ev * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+    # the same evaluation as RankingMetrics.evaluate consumes it: ranks of the held-out items only, no top-10 list
+    # (dr_score_rank_f32; every metric of RankingMetrics.py:21-65 is a function of those ranks)
+    t_rk = ev_time(lambda: K.score_rank(Uemb, Q, (gp, tg), train=(tp, tr.reshape(-1).contiguous())), 3, stream)
+    out["eval"]["ranks_only"] = {"avg_ms": t_rk, "users_per_s": Nu / (t_rk * 1e-3), "TFLOPs": flops / (t_rk * 1e-3) / 1e12,
+                                 "frac_mfma_f32_peak": flops / (t_rk * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS}
     return out
 
 

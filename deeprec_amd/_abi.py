@@ -62,6 +62,7 @@ SIGNATURES = {
     "dr_score_topk_bytes": (_i64, [_i64, _i64, _i32, _i32, _i64, _i32]),
     "dr_score_topk_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _p, _p, _p, _p, _i64, _i32,
                                  _p, _p, _p, _p, _i64, _p]),
+    "dr_score_rank_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _p, _p, _p, _p, _i64, _p, _p, _i64, _p]),
     "dr_score_rank_exact_bytes": (_i64, [_i64, _i64, _i32, _i64, _i32]),
     "dr_score_rank_exact_f32": (_i32, [_p, _p, _i64, _p, _p, _p, _i64, _i32, _i32, _f, _f, _p, _p, _p, _p, _i64, _p, _p,
                                        _i64, _p]),

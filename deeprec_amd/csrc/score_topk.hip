@@ -484,19 +484,19 @@ __device__ __forceinline__ constexpr int kpos(int c) {
 // elements per row (power of two covering the widest chunk of this instantiation), thread th owns column
 // element th % CPT of rows th / CPT + q * RPP.  Global addresses are (uniform tile base) + (per-thread
 // constant 32-bit offset); LDS addresses are (per-thread constant) + immediates.
-template <int KS, bool VEC>
+template <int KS, bool VEC, int NT = 256>
 struct Geo {
     static constexpr int W = VEC ? 8 : 1;
     static constexpr int CPT = VEC ? (KS >= 64 ? 16 : 8) : (KS >= 64 ? 128 : 64);
-    static constexpr int RPP = 256 / CPT;
+    static constexpr int RPP = NT / CPT;
     static constexpr int PASSES = TI / RPP;
     static constexpr int NPRE = PASSES * W;
 };
 
-template <int KS, bool VEC, int N>
+template <int KS, bool VEC, int N, int NT = 256>
 __device__ __forceinline__ void prefetch_chunk(float (&pre)[N], const float* __restrict__ I, int64_t i0, int64_t Ni,
                                                int k, int kc0, int r0, int gc) {
-    using G = Geo<KS, VEC>;
+    using G = Geo<KS, VEC, NT>;
     const char* tile = reinterpret_cast<const char*>(I) + (i0 * k + kc0) * 4;  // uniform
     const bool full = i0 + TI <= Ni;
     const int rmax = full ? TI : (int)(Ni - 1 - i0);   // ragged last tile: rows beyond Ni re-read the last valid
@@ -524,9 +524,9 @@ __device__ __forceinline__ void prefetch_chunk(float (&pre)[N], const float* __r
 
 // d = sI + r0 * LDP + (VEC ? g * 8 + 4 * ((g >> 2) & 1) : kpos(g)): where the even k of the thread's group go (VEC: the
 // odd k go to the other half of the group, d ^ 16 bytes)
-template <int KS, bool VEC, int N>
+template <int KS, bool VEC, int N, int NT = 256>
 __device__ __forceinline__ void store_chunk(float* __restrict__ d, float* __restrict__ dodd, const float (&pre)[N]) {
-    using G = Geo<KS, VEC>;
+    using G = Geo<KS, VEC, NT>;
 #pragma unroll
     for (int q = 0; q < G::PASSES; ++q) {
         if (VEC) {
@@ -1042,6 +1042,320 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
         atomicAdd(a.tgt_rank + a.tgt_ptr[u0 + tid], tcnt[tid]);
 }
 
+// ---- rank only (round 3): k <= 256, at most ONE held-out item per user, no top-K list ---------------------------
+// What the reference's evaluators consume is the RANK of the held-out item among the candidates (SeqRecMetrics.py:33,59,
+// 75-80: HR@50 / MRR / AUC; RankingMetrics.py:31,52 likewise) -- a count of the scores that beat the held-out item's.
+// Without a list to maintain, a tile costs per lane 16 compares whose results are counted by SCALAR popcounts of the
+// ballots (32 row counters per wave in scalar registers; fp32 MFMA shares the vector pipe with ordinary vector work,
+// the scalar unit is free) and 16 tie tests; there is no score tile, no candidate word, no row owner.  Train items are
+// not looked at in the stream at all: every score is counted, and afterwards the panel's train items are scored ONCE MORE
+// as gathered "correction" tiles through the same MFMA sequence (so each (user, item) score has the same bits as in the
+// stream) and the ones that had beaten the held-out item are taken off the count -- 64 train entries per extra tile,
+// ~1 % of the stream at C4 / C5.  The item tile is double-buffered in LDS (2 x 33 KB, two workgroups per CU): ONE
+// barrier per k-chunk, and the store of the next chunk is followed by the MFMA chain instead of a barrier.
+// LDS after the two item-tile buffers, for a panel of TUK users (floats / ints):
+//   [TUK] held-out score (+inf: none) | [TUK] held-out item (-1: none / masked) | [TUK] rank counters |
+//   [TUK + 4] train_ptr of the panel's users | [TI] correction tile: train item of column c (-1: none) | [TI] its panel row
+// Panel height (template WU = waves of 32 users; two waves of 32 items each): k <= 128 runs 128-user panels (ONE
+// workgroup of 8 waves per CU: every staged item tile serves twice the MFMA work; C4 shape 0.655 of peak against 0.634
+// with two 64-user workgroups per CU) once there are enough users to fill the chip that way, 128 < k <= 256 stays at 64
+// users (the 128-register user panel + 8 waves per CU leaves 256 registers per wave: 40-60 spill to memory, 0.46
+// against 0.58).
+#ifndef RK_CNT
+#define RK_CNT 1   // 1: per-lane vector counters; 0: row counters in scalar registers (ballot + popcount: the 32 counters do
+                   // not fit the scalar file beside the kernel's other state -- 80 v_readlane / v_writelane per two tiles)
+#endif
+// prefetch_chunk for a gathered tile: row r of the tile is item rows[r] (LDS; < 0: any valid row, never looked at)
+template <int KS, bool VEC, int N, int NT>
+__device__ __forceinline__ void prefetch_rows(float (&pre)[N], const float* __restrict__ I, const int* rows, int k, int kc0,
+                                              int r0, int gc) {
+    using G = Geo<KS, VEC, NT>;
+#pragma unroll
+    for (int q = 0; q < G::PASSES; ++q) {
+        int m = rows[r0 + q * G::RPP];
+        m = m < 0 ? 0 : m;
+        const float* p = I + (int64_t)m * k + kc0 + gc * G::W;
+        if (VEC) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p);
+            const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+            pre[8 * q] = v0.x; pre[8 * q + 1] = v0.y; pre[8 * q + 2] = v0.z; pre[8 * q + 3] = v0.w;
+            pre[8 * q + 4] = v1.x; pre[8 * q + 5] = v1.y; pre[8 * q + 6] = v1.z; pre[8 * q + 7] = v1.w;
+        } else {
+            pre[q] = *p;
+        }
+    }
+}
+
+template <int KS, bool VEC, bool AFFINE, int WU, bool BAND>
+__global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 64)) ? 2 : 1) void score_rank_kernel(ScoreArgs a) {
+    constexpr int NT = 128 * WU, TUK = 32 * WU;     // WU waves of 32 users x 2 waves of 32 items
+    using G = Geo<KS, VEC, NT>;
+    constexpr int NCH = (2 * KS + KC - 1) / KC;      // k-chunks per tile: 1 (k <= 128) or 2 (this instantiation: k > 128)
+    constexpr int JPC = KS < KC / 2 ? KS : KC / 2;
+    constexpr int BUF = TI * LDP;
+    if (*a.mode_flag != 0) return;  // some user has several held-out items: score_kernel handles this call
+    extern __shared__ __align__(16) float smem[];
+    float* sI = smem;               // [2][TI][LDP], k-permuted (see LDP); with two chunks buffer c always holds chunk c
+    float* base = smem + 2 * BUF;
+    float* tsc = base;
+    int* tidl = reinterpret_cast<int*>(base + TUK);
+    int* tcnt = reinterpret_cast<int*>(base + 2 * TUK);
+    int* tptr = reinterpret_cast<int*>(base + 3 * TUK);
+    int* mitem = reinterpret_cast<int*>(base + 4 * TUK + 4);
+    int* mrow = mitem + TI;
+    float* tlo = reinterpret_cast<float*>(mrow + TI);      // BAND: lower end of the held-out item's band
+    int* tslot = reinterpret_cast<int*>(tlo + TUK);        // BAND: its slot in the target CSR
+    int* wmax = tslot + TUK;                               // BAND: widest band of the panel (float bits)
+    if (threadIdx.x == 0) *wmax = 0;
+    __syncthreads();
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wu = wave >> 1, wi = wave & 1;
+    const int64_t u0 = (int64_t)blockIdx.x * TUK;
+    const int t_begin = blockIdx.y * a.tiles_per_split;
+    int t_end = t_begin + a.tiles_per_split;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    const int k = a.k;
+
+    float areg[KS];
+    load_areg<KS>(areg, a, u0, wu, lane);
+    for (int e = tid; e < 2 * BUF; e += NT) sI[e] = 0.0f;   // columns that no chunk store touches read as zero
+    if (tid < TUK) {
+        const int64_t u = u0 + tid;
+        tcnt[tid] = 0;
+        float sc = INFINITY, lo = INFINITY;
+        int id = -1, slot = 0;
+        if (a.tgt_ptr && u < a.Nu) {
+            const int p = a.tgt_ptr[u];
+            if (a.tgt_ptr[u + 1] > p && !a.tgt_masked[p]) {
+                // BAND (dr_score_rank_exact_f32): a score above tgt_hi counts, one inside [tgt_score, tgt_hi] goes to the
+                // exact re-score; otherwise tgt_score is the held-out item's own score
+                sc = BAND ? a.tgt_hi[p] : a.tgt_score[p];
+                lo = a.tgt_score[p];
+                id = a.tgt_idx[p];
+                slot = p;
+            }
+        }
+        tsc[tid] = sc;
+        tidl[tid] = id;
+        tlo[tid] = lo;
+        tslot[tid] = slot;
+        if (BAND && id >= 0) atomicMax(wmax, __float_as_int(sc - lo));   // widths are >= 0: their bit patterns order like ints
+    }
+    if (tid <= TUK) tptr[tid] = a.train_ptr ? a.train_ptr[(u0 + tid < a.Nu) ? u0 + tid : a.Nu] : 0;
+    float ua[16];
+    if (AFFINE) load_uadd(ua, a, u0, wu, lane);
+    const int mycol = wi * 32 + (lane & 31);
+    const int rbase = wu * 32 + 4 * (lane >> 5);   // row of accumulator element r = rbase + (r&3) + 8*(r>>2)
+
+    const int g = tid % G::CPT, r0 = tid / G::CPT;
+    const int kc_first = k < KC ? k : KC;
+    const bool live0 = g * G::W < kc_first;
+    const bool live1 = NCH > 1 && g * G::W < k - KC;
+    const int gc0 = live0 ? g : 0, gc1 = live1 ? g : 0;
+    float* dst = sI + r0 * LDP + (VEC ? g * 8 + 4 * ((g >> 2) & 1) : kpos(g));
+    float* dst_odd = sI + r0 * LDP + (VEC ? g * 8 + 4 * (1 - ((g >> 2) & 1)) : kpos(g));
+    const float* pb = sI + mycol * LDP + 4 * (lane >> 5);
+    const float* pbx = sI + mycol * LDP + 4 * (1 - (lane >> 5));
+    const int ng0 = (kc_first + 15) >> 4, ng1 = NCH > 1 ? ((k - KC + 15) >> 4) : 0;
+
+    __syncthreads();
+    float stR[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stR[r] = tsc[rbase + (r & 3) + 8 * (r >> 2)];
+    // BAND: the stream only asks "within the panel's WIDEST band below hi?" (one scalar, no second threshold per row in
+    // registers; padded so that rounding of the sum cannot lose a score on a band's lower end); the row's own lower end is
+    // read from LDS on the rare path
+    const float wpad = BAND ? __int_as_float(*wmax) * 1.000002f + 1e-37f : 0.0f;
+    auto band_append = [&](int row, int item_word) {
+        const int p = atomicAdd(a.band_count, 1);
+        if (p < a.band_cap) {
+            a.band_list[3 * (int64_t)p] = (int32_t)(u0 + row);
+            a.band_list[3 * (int64_t)p + 1] = tslot[row];
+            a.band_list[3 * (int64_t)p + 2] = item_word;
+        }
+    };
+    int cA[16], cB[16];                            // wave-uniform: rows wu*32 + (r&3) + 8*(r>>2) and those + 4
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cA[r] = cB[r] = 0;
+
+    // stage s = (tile t_begin + s / NCH, chunk s % NCH) lives in buffer s & 1; `pre` holds stage s + 1 while s computes
+    const int nst = (t_end - t_begin) * NCH;
+    float pre[G::NPRE];
+    float ia_next = -0.0f;
+    if (nst > 0) {
+        prefetch_chunk<KS, VEC, G::NPRE, NT>(pre, a.I, (int64_t)t_begin * TI, a.Ni, k, 0, r0, gc0);
+        if (AFFINE) ia_next = load_iadd(a, (int64_t)t_begin * TI + mycol);
+        if (live0) store_chunk<KS, VEC, G::NPRE, NT>(dst, dst_odd, pre);
+        if (nst > 1) {
+            if (NCH > 1) prefetch_chunk<KS, VEC, G::NPRE, NT>(pre, a.I, (int64_t)t_begin * TI, a.Ni, k, KC, r0, gc1);
+            else prefetch_chunk<KS, VEC, G::NPRE, NT>(pre, a.I, (int64_t)(t_begin + 1) * TI, a.Ni, k, 0, r0, gc0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __syncthreads();
+
+    int s = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int64_t i0 = (int64_t)t * TI;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float ia = ia_next;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c, ++s) {
+            const int cur = (NCH > 1) ? c : (s & 1);
+            const int oth = cur ^ 1;
+            // stage s + 1 (in registers since the previous stage's MFMA chain) -> the other buffer: its last readers
+            // passed the barrier that ended stage s - 1
+            if (s + 1 < nst) {
+                const bool lv = (NCH > 1 && c == 0) ? live1 : live0;
+                if (lv) store_chunk<KS, VEC, G::NPRE, NT>(dst + oth * BUF, dst_odd + oth * BUF, pre);
+            }
+            if (s + 2 < nst) {   // stage s + 2 -> registers, in flight during this stage's MFMAs
+                if (NCH > 1) prefetch_chunk<KS, VEC, G::NPRE, NT>(pre, a.I, i0 + TI, a.Ni, k, c * KC, r0, c == 0 ? gc0 : gc1);
+                else prefetch_chunk<KS, VEC, G::NPRE, NT>(pre, a.I, i0 + 2 * TI, a.Ni, k, 0, r0, gc0);
+            }
+            if (AFFINE && c == NCH - 1 && t + 1 < t_end) ia_next = load_iadd(a, i0 + TI + mycol);
+            mfma_chunk<JPC / 8>(acc, areg + c * (KC / 2), pb + cur * BUF, pbx + cur * BUF, c == 0 ? ng0 : ng1);
+            if (c == NCH - 1) {
+                if (AFFINE) {
+                    const float cd = a.cdot;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float sc = cd * acc[r];
+                        sc = sc + ua[r];
+                        acc[r] = sc + ia;
+                    }
+                }
+                if (t == a.ntiles - 1 && ((int)a.Ni & (TI - 1)) != 0 && mycol >= ((int)a.Ni & (TI - 1))) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = -INFINITY;   // columns beyond the catalog beat nothing
+                }
+                unsigned long long eq = 0ull;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#if RK_CNT == 0
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(acc[r] > stR[r]);
+                    cA[r] += __builtin_popcount((unsigned)m);
+                    cB[r] += __builtin_popcount((unsigned)(m >> 32));
+#else
+                    cA[r] += (acc[r] > stR[r]) ? 1 : 0;
+#endif
+                    if (BAND) eq |= __builtin_amdgcn_ballot_w64(acc[r] <= stR[r] && acc[r] + wpad >= stR[r]);
+                    else eq |= __builtin_amdgcn_ballot_w64(acc[r] == stR[r]);
+                }
+                if (eq) {   // a tie with the held-out item (or the item itself): decided by item id; BAND: inside the band
+                    const int item = (int)i0 + mycol;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (BAND) {
+                            const bool near = acc[r] <= stR[r] && acc[r] + wpad >= stR[r];
+                            if (__builtin_amdgcn_ballot_w64(near) == 0ull) continue;      // uniform: nothing for this r
+                            if (near && acc[r] >= tlo[row]) {
+                                const int ct = tidl[row];
+                                if (ct >= 0 && item != ct) band_append(row, item);
+                            }
+                        } else if (acc[r] == stR[r]) {
+                            const int ct = tidl[row];
+                            if (ct >= 0 && item < ct) atomicAdd(&tcnt[row], 1);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __syncthreads();
+        }
+    }
+#if RK_CNT == 0
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wu * 32 + (r & 3) + 8 * (r >> 2);
+            if (cA[r]) atomicAdd(&tcnt[row], cA[r]);
+            if (cB[r]) atomicAdd(&tcnt[row + 4], cB[r]);
+        }
+    }
+#else
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (cA[r]) atomicAdd(&tcnt[rbase + (r & 3) + 8 * (r >> 2)], cA[r]);
+#endif
+    // ---- correction tiles: the panel's train items inside this split's item range, 64 entries per tile
+    if (a.train_ptr) {
+        const int E0 = tptr[0], E1 = tptr[TUK];
+        const int lo_item = t_begin * TI;
+        const int64_t hi64 = (int64_t)t_end * TI < a.Ni ? (int64_t)t_end * TI : a.Ni;
+        const int hi_item = (int)hi64;
+        for (int e0 = E0; e0 < E1; e0 += TI) {
+            __syncthreads();                   // the previous tile's readers of mitem / mrow / sI are done
+            int item = -1;
+            if (tid < TI) {
+                const int e = e0 + tid;
+                int row = 0;
+                if (e < E1) {
+                    const int m = a.train_idx[e];
+                    if (m >= lo_item && m < hi_item) {
+                        item = m;
+                        int lo = 0, hi = TUK;  // the row whose train range holds entry e: last x with tptr[x] <= e
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (tptr[mid] <= e) lo = mid; else hi = mid - 1;
+                        }
+                        row = lo;
+                        if (tidl[row] < 0) item = -1;   // no held-out item in that row: nothing to correct
+                        if (e > tptr[row] && a.train_idx[e - 1] == m) item = -1;   // a repeated entry masks only once
+                    }
+                }
+                mitem[tid] = item;
+                mrow[tid] = row;
+            }
+            if (!__syncthreads_or(item >= 0)) continue;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            float prc[G::NPRE];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                prefetch_rows<KS, VEC, G::NPRE, NT>(prc, a.I, mitem, k, c * KC, r0, c == 0 ? gc0 : gc1);
+                if (c == 0 ? live0 : live1) store_chunk<KS, VEC, G::NPRE, NT>(dst + c * BUF, dst_odd + c * BUF, prc);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                mfma_chunk<JPC / 8>(acc, areg + c * (KC / 2), pb + c * BUF, pbx + c * BUF, c == 0 ? ng0 : ng1);
+            const int it = mitem[mycol], rw = mrow[mycol];
+            if (it >= 0) {
+                const float ia2 = AFFINE ? load_iadd(a, it) : -0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row == rw) {
+                        float sc = acc[r];
+                        if (AFFINE) {
+                            sc = a.cdot * sc;
+                            sc = sc + ua[r];
+                            sc = sc + ia2;
+                        }
+                        const int ct = tidl[row];
+                        if (BAND) {
+                            // counted in the stream -> taken off; listed in the stream -> a cancelling entry (bit 31)
+                            if (ct >= 0 && sc > stR[r]) atomicSub(&tcnt[row], 1);
+                            else if (ct >= 0 && sc >= tlo[row] && sc <= stR[r] && it != ct) band_append(row, it | (int)0x80000000);
+                        } else if (ct >= 0 && beats(sc, it, stR[r], ct)) atomicSub(&tcnt[row], 1);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (a.tgt_ptr && tid < TUK && u0 + tid < a.Nu && tcnt[tid] != 0 && tidl[tid] >= 0)
+        atomicAdd(a.tgt_rank + a.tgt_ptr[u0 + tid], tcnt[tid]);
+}
+
 // 1 in *flag when some user has more than one held-out item (flag is zeroed before the launch)
 __global__ __launch_bounds__(256) void target_mode_kernel(const int32_t* __restrict__ tgt_ptr, int64_t Nu,
                                                           int32_t* __restrict__ flag) {
@@ -1331,6 +1645,39 @@ static int launch_score_t1(const ScoreArgs& a, dim3 grid, hipStream_t st) {
     return vec ? launch_score_t1_k<64, true>(a, grid, st) : launch_score_t1_k<64, false>(a, grid, st);
 }
 
+// grid.y = item splits (as for the other kernels); grid.x is computed here from the kernel's own panel height
+template <int KS, bool VEC, bool AFFINE, int WU, bool BAND>
+static int launch_score_rank_kaw(const ScoreArgs& a, unsigned splits, hipStream_t st) {
+    const size_t smem = ((size_t)2 * TI * LDP + 6 * 32 * WU + 8 + 2 * TI) * 4;
+    const int64_t panels = (a.Nu + 32 * WU - 1) / (32 * WU);
+    DR_HIP(hipFuncSetAttribute((const void*)score_rank_kernel<KS, VEC, AFFINE, WU, BAND>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    DR_LAUNCH_NAMED("score_rank_kernel", (score_rank_kernel<KS, VEC, AFFINE, WU, BAND>), dim3((unsigned)panels, splits),
+                    dim3(128 * WU), smem, st, a);
+    DR_CHECK_LAUNCH("score_rank_kernel");
+    return DR_OK;
+}
+template <int KS, bool VEC, int WU, bool BAND>
+static int launch_score_rank_k(const ScoreArgs& a, unsigned splits, hipStream_t st) {
+    const bool affine = a.uadd || a.iadd || a.cdot != 1.0f;
+    return affine ? launch_score_rank_kaw<KS, VEC, true, WU, BAND>(a, splits, st)
+                  : launch_score_rank_kaw<KS, VEC, false, WU, BAND>(a, splits, st);
+}
+template <bool BAND>
+static int launch_score_rank(const ScoreArgs& a, unsigned splits, hipStream_t st) {   // k <= 256
+    const bool vec = (a.k & 7) == 0;
+    const bool tall = !BAND && vec && a.Nu >= 128 * 128;      // 128-user panels: >= 128 workgroups before the item splits
+    if (a.k <= 64) {
+        if (tall) return launch_score_rank_k<32, true, 4, false>(a, splits, st);
+        return vec ? launch_score_rank_k<32, true, 2, BAND>(a, splits, st) : launch_score_rank_k<32, false, 2, BAND>(a, splits, st);
+    }
+    if (a.k <= 128) {
+        if (tall) return launch_score_rank_k<64, true, 4, false>(a, splits, st);
+        return vec ? launch_score_rank_k<64, true, 2, BAND>(a, splits, st) : launch_score_rank_k<64, false, 2, BAND>(a, splits, st);
+    }
+    return vec ? launch_score_rank_k<128, true, 2, BAND>(a, splits, st) : launch_score_rank_k<128, false, 2, BAND>(a, splits, st);
+}
+
 // grid = (64-user panels, item splits)
 template <bool MATRIX>
 static int launch_score(const ScoreArgs& a, dim3 grid, hipStream_t st) {
@@ -1574,9 +1921,10 @@ __global__ __launch_bounds__(256) void exact_refine_kernel(ExactArgs e, const in
     for (int64_t y = (int64_t)blockIdx.x * 256 + threadIdx.x; y < n; y += (int64_t)gridDim.x * 256) {
         const int64_t u = band_list[3 * y];
         const int x = band_list[3 * y + 1];
-        const int item = band_list[3 * y + 2];
-        const float s = ref_order_score(e, u, item);
-        if (s == s && beats(s, item, tgt_ref[x], tgt_idx[x])) atomicAdd(tgt_rank + x, 1);
+        const int word = band_list[3 * y + 2];
+        const int item = word & 0x7fffffff;      // bit 31: a train item that the rank-only kernel listed in its stream --
+        const float s = ref_order_score(e, u, item);                      // the entry cancels the listing
+        if (s == s && beats(s, item, tgt_ref[x], tgt_idx[x])) atomicAdd(tgt_rank + x, word < 0 ? -1 : 1);
     }
 }
 
@@ -1749,6 +2097,72 @@ extern "C" int32_t dr_score_topk_f32(const float* U, const float* U2, int64_t Nu
     return DR_OK;
 }
 
+extern "C" int32_t dr_score_rank_f32(const float* U, const float* U2, int64_t Nu, const float* I, const float* I2,
+                                     const float* item_bias, int64_t Ni, int32_t k, int32_t score_kind, float alpha,
+                                     const int32_t* train_ptr, const int32_t* train_idx, const int32_t* tgt_ptr,
+                                     const int32_t* tgt_idx, int64_t n_targets, int32_t* tgt_rank, void* ws,
+                                     int64_t ws_bytes, void* stream) {
+    int rc = check_score_args(U, U2, Nu, I, I2, Ni, k, score_kind, "dr_score_rank_f32");
+    if (rc != DR_OK) return rc;
+    DR_REQUIRE(n_targets >= 0 && (n_targets == 0 || (tgt_ptr && tgt_idx && tgt_rank)),
+               "dr_score_rank_f32: target CSR / rank output is NULL");
+    DR_REQUIRE((train_ptr == nullptr) == (train_idx == nullptr) || train_ptr, "dr_score_rank_f32: train CSR incomplete");
+    DR_REQUIRE(ws && ((uintptr_t)ws % 256 == 0), "dr_score_rank_f32: workspace NULL / misaligned");
+    if (Nu == 0 || n_targets == 0) return DR_OK;
+    TopkLayout L;
+    topk_layout(Nu, Ni, k, 1, n_targets, score_kind, &L);
+    if (ws_bytes < L.total)
+        DR_FAIL(DR_ERR_WORKSPACE, "dr_score_rank_f32: workspace %lld < required %lld", (long long)ws_bytes,
+                (long long)L.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)ws;
+    ScoreArgs a;
+    memset(&a, 0, sizeof(a));
+    rc = prepare_operands(U, U2, Nu, I, I2, item_bias, Ni, k, score_kind, alpha, 1.0f - alpha, base, L, st, &a);
+    if (rc != DR_OK) return rc;
+    a.Nu = Nu;
+    a.Ni = Ni;
+    a.train_ptr = train_ptr;
+    a.train_idx = train_idx;
+    a.K = 1;                                   // the general kernel (several held-out items per user) keeps a 1-list
+    a.ntiles = L.ntiles;
+    a.tiles_per_split = L.tiles_per_split;
+    a.part_v = (float*)(base + L.part_v);
+    a.part_i = (int32_t*)(base + L.part_i);
+    a.tgt_ptr = tgt_ptr;
+    a.tgt_idx = tgt_idx;
+    a.tgt_score = (float*)(base + L.tgt_score);
+    a.tgt_masked = (int32_t*)(base + L.tgt_masked);
+    a.tgt_rank = tgt_rank;
+    DR_LAUNCH(target_prologue_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, a.U, a.I, a.uadd, a.iadd, a.cdot, Nu, Ni,
+              a.k, (const float*)nullptr, train_ptr, train_idx, tgt_ptr, tgt_idx, (float*)(base + L.tgt_score),
+              (int32_t*)(base + L.tgt_masked), tgt_rank);
+    DR_CHECK_LAUNCH("target_prologue_kernel");
+    if (Ni > 0) {
+        const int64_t panels = (Nu + TU - 1) / TU;
+        DR_REQUIRE(panels < (1ll << 31), "dr_score_rank_f32: too many user panels");
+        const dim3 grid((unsigned)panels, (unsigned)L.S);
+        // the rank-only kernel serves calls in which no user has more than one held-out item, the general kernel the
+        // others: a device-side fact (the target CSR), so both are enqueued and the one not in charge returns at once
+        const bool fast = a.k <= 256 && n_targets <= Nu;
+        if (fast) {
+            int32_t* flag = (int32_t*)(base + L.mode);
+            DR_HIP(hipMemsetAsync(flag, 0, 4, st));
+            a.mode_flag = flag;
+            DR_LAUNCH(target_mode_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, tgt_ptr, Nu, flag);
+            DR_CHECK_LAUNCH("target_mode_kernel");
+            rc = launch_score_rank<false>(a, (unsigned)L.S, st);
+            if (rc != DR_OK) return rc;
+        }
+        rc = launch_score<false>(a, grid, st);
+        if (rc != DR_OK) return rc;
+    }
+    DR_LAUNCH(target_finalize_kernel, dim3(grid_for(n_targets, 256)), dim3(256), 0, st,
+              (const int32_t*)(base + L.tgt_masked), n_targets, tgt_rank);
+    DR_CHECK_LAUNCH("target_finalize_kernel");
+    return DR_OK;
+}
+
 extern "C" int32_t dr_score_matrix_f32(const float* U, const float* U2, int64_t Nu, const float* I, const float* I2,
                                        const float* item_bias, int64_t Ni, int32_t k, int32_t score_kind, float alpha,
                                        int32_t act, float* out, void* ws, int64_t ws_bytes, void* stream) {
@@ -1899,6 +2313,17 @@ extern "C" int32_t dr_score_rank_exact_f32(const float* U, const float* U2, int6
     DR_CHECK_LAUNCH("exact_prologue_kernel");
     const int64_t panels = (Nu + TU - 1) / TU;
     DR_REQUIRE(panels < (1ll << 31), "dr_score_rank_exact_f32: too many user panels");
+    if (a.k <= 256 && n_targets <= Nu && Ni > 0) {
+        // no user with more than one held-out item (a device-side fact): the rank-only kernel is in charge and the general
+        // one returns at once
+        int32_t* flag = (int32_t*)(base + L.mode);
+        DR_HIP(hipMemsetAsync(flag, 0, 4, st));
+        a.mode_flag = flag;
+        DR_LAUNCH(target_mode_kernel, dim3(grid_for(Nu, 256)), dim3(256), 0, st, tgt_ptr, Nu, flag);
+        DR_CHECK_LAUNCH("target_mode_kernel");
+        rc = launch_score_rank<true>(a, (unsigned)L.S, st);
+        if (rc != DR_OK) return rc;
+    }
     rc = launch_score_band(a, dim3((unsigned)panels, (unsigned)L.S), st);
     if (rc != DR_OK) return rc;
     DR_LAUNCH(exact_refine_kernel, dim3(grid_for(E.band_cap < (1 << 22) ? E.band_cap : (1 << 22), 256)), dim3(256), 0, st, e,

@@ -1027,6 +1027,32 @@ def score_topk(U, I, K, score_kind=SCORE_DOT, U2=None, I2=None, alpha=0.0, item_
     return topk_idx, topk_score, rank
 
 
+def score_rank(U, I, targets, score_kind=SCORE_DOT, U2=None, I2=None, alpha=0.0, item_bias=None, train=None):
+    """dr_score_rank_f32: the ranks score_topk returns, without a top-K list (what the evaluators consume).
+    targets / train: (ptr[Nu+1], idx[nnz]) int32 CSR.  Returns tgt_rank[nnz] int32 (-1: the held-out item is masked)."""
+    U = _req(U, torch.float32, "U", 2)
+    I = _req(I, torch.float32, "I", 2)
+    Nu, k = U.shape
+    Ni = I.shape[0]
+    if I.shape[1] != k:
+        raise ValueError("U and I must share k")
+    if score_kind == SCORE_TWO_DIST:
+        if tuple(_req(U2, torch.float32, "U2", 2).shape) != (Nu, k) or tuple(_req(I2, torch.float32, "I2", 2).shape) != (Ni, k):
+            raise ValueError("U2 / I2 must match U / I")
+    if item_bias is not None and _req(item_bias, torch.float32, "item_bias", 1).numel() != Ni:
+        raise ValueError("item_bias must be [Ni]")
+    tp, ti = _csr(*(train if train is not None else (None, None)), Nu, "train")
+    gp, gi = _csr(*targets, Nu, "tgt")
+    nt = gi.numel()
+    rank = torch.zeros(nt, dtype=torch.int32, device=U.device)
+    need = check(_abi.lib().dr_score_topk_bytes(Nu, Ni, k, 1, nt, score_kind), "dr_score_topk_bytes")
+    ws = torch.empty(max(need, 256), dtype=torch.uint8, device=U.device)
+    check(_abi.lib().dr_score_rank_f32(_ptr(U), _ptr(U2), Nu, _ptr(I), _ptr(I2), _ptr(item_bias), Ni, k, score_kind,
+                                       float(alpha), _ptr(tp), _ptr(ti), _ptr(gp), _ptr(gi), nt, _ptr(rank), _ptr(ws),
+                                       ws.numel(), _stream()), "dr_score_rank_f32")
+    return rank
+
+
 def score_rank_exact(U, I, targets, score_kind=SCORE_DOT, U2=None, I2=None, w1=0.0, w2=0.0, item_bias=None, train=None):
     """Ranks of the held-out items in the reference's numpy float32 operation order (dr_score_rank_exact_f32):
     MFMA pass + exact re-score of the near-ties.  targets / train: (ptr, idx) int32 CSR.  Returns int32 [nnz]."""

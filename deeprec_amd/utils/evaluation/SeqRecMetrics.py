@@ -3,7 +3,7 @@
 evaluate1 (AttRec / PRME two-distance score, SeqRecMetrics.py:91-177), evaluate_caser (GEMM + item bias,
 :179-248) and evaluate (per-user predict, :250-295) keep their protocol (getUserParam / getItemParam /
 predict, test_users, neg_items, test_data, num_item, alpha) and printed lines; scoring, masking and ranking
-run in one dr_score_topk_f32 launch.  Each returns the dict of means it prints.
+run in one dr_score_rank_f32 / dr_score_rank_exact_f32 call (ranks only: no top-K list is kept).  Each returns the dict of means it prints.
 
 Deviation kept explicit: the reference indexes `results[u, j]` with the user ID while `results` holds one
 row per entry of test_users (SeqRecMetrics.py:107,141) -- only consistent when test_users == range(n).
@@ -55,10 +55,10 @@ def _rank(self, users, U, I, kind, U2=None, I2=None, alpha=0.0, bias=None, score
                                    w1=np.float32(alpha), w2=np.float32(1 - alpha),
                                    item_bias=None if bias is None else _t(bias, dev).reshape(-1), train=(tp, ti))
     else:
-        _, _, rank = Kn.score_topk(_t(U, dev), _t(I, dev), 1, score_kind=kind,
-                                   U2=None if U2 is None else _t(U2, dev), I2=None if I2 is None else _t(I2, dev),
-                                   alpha=alpha, item_bias=None if bias is None else _t(bias, dev).reshape(-1),
-                                   train=(tp, ti), targets=(gp, gi))
+        # ranks only (dr_score_rank_f32): with one held-out item per user the streaming kernel keeps no list at all
+        rank = Kn.score_rank(_t(U, dev), _t(I, dev), (gp, gi), score_kind=kind,
+                             U2=None if U2 is None else _t(U2, dev), I2=None if I2 is None else _t(I2, dev),
+                             alpha=alpha, item_bias=None if bias is None else _t(bias, dev).reshape(-1), train=(tp, ti))
     return split_ranks(rank, tgt), [num_item - len(m) for m in masked]
 
 

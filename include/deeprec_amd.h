@@ -301,6 +301,18 @@ int32_t dr_topk_rank_f32(const float* scores, int64_t Nu, int64_t Ni, const int3
                          int64_t n_targets, int32_t K, int32_t* topk_idx, float* topk_score,
                          int32_t* tgt_rank, void* ws, int64_t ws_bytes, void* stream);
 
+/* Ranks only: tgt_rank as dr_score_topk_f32 computes it, without a top-K list -- what the reference's evaluators consume
+ * (SeqRecMetrics.py:33,59,75-80: HR@50 / MRR / AUC depend on the ranked list only through the position of the held-out
+ * items; RankingMetrics.py:31,52 likewise).  k <= 256 with at most one held-out item per user runs a streaming kernel
+ * whose per-tile epilogue is 16 compares per lane counted by scalar popcounts; train items are taken off the count
+ * afterwards from gathered correction tiles scored by the same MFMA sequence (bit-identical scores).  Other calls run
+ * dr_score_topk_f32's kernels with K = 1.  Same scores, ties and masking rules; ws: dr_score_topk_bytes(..., K = 1, ...). */
+int32_t dr_score_rank_f32(const float* U, const float* U2, int64_t Nu, const float* I, const float* I2,
+                          const float* item_bias, int64_t Ni, int32_t k, int32_t score_kind, float alpha,
+                          const int32_t* train_ptr, const int32_t* train_idx, const int32_t* tgt_ptr,
+                          const int32_t* tgt_idx, int64_t n_targets, int32_t* tgt_rank, void* ws, int64_t ws_bytes,
+                          void* stream);
+
 /* Dense score matrix out[Nu, Ni] through the same MFMA GEMM (GMF.predict over a catalog,
  * gmf.py:160-161 with act = 1 (sigmoid); SeqRecMetrics.py:122-123, 213 with act = 0).
  * Distance kinds need a workspace of dr_score_topk_bytes(Nu, Ni, k, 1, 0, kind). */

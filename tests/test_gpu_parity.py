@@ -576,11 +576,51 @@ def test_score_kernel_instantiations_repeatable_and_exact(dev, k, kind, ntgt):
             _check_selection(scores, train, tgt, K_, N(idx), N(val), N(rank))
         else:
             assert torch.equal(idx, first[0]) and torch.equal(val, first[1]) and torch.equal(rank, first[2])
+    # the rank-only kernels (dr_score_rank_f32; score_rank_kernel when no user has more than one held-out item): the same
+    # ranks without a list -- train items counted in the stream and taken off again from gathered correction tiles
+    for _ in range(3):
+        assert torch.equal(K.score_rank(tU, tI, tg, score_kind=kind, train=tr), first[2])
+    if ntgt == 1:
+        ib = (rng.standard_normal(Ni) * 0.05).astype(np.float32)
+        _, _, rk = K.score_topk(tU, tI, 1, score_kind=kind, item_bias=T(ib, dev), train=tr, targets=tg)
+        assert torch.equal(K.score_rank(tU, tI, tg, score_kind=kind, item_bias=T(ib, dev), train=tr), rk)
+        assert torch.equal(K.score_rank(tU, tI, tg, score_kind=kind), K.score_topk(tU, tI, 1, score_kind=kind, targets=tg)[2])
     # the band instantiations (dr_score_rank_exact_f32) on the same inputs: repeatable and equal to numpy's order
     want = _exact_ranks(ro.numpy_order_scores(kind, U, I), train, tgt)
     for _ in range(2):
         r = N(K.score_rank_exact(tU, tI, tg, score_kind=kind, train=tr))
         assert np.array_equal(r, want)
+
+
+@pytest.mark.parametrize("k,kind", [(64, 0), (128, 1), (40, 2)])
+def test_score_rank_tall_panels(dev, k, kind):
+    """dr_score_rank_f32 with >= 16 384 users and k <= 128: the rank-only kernel runs 128-user panels (one workgroup of
+    8 waves); ranks equal dr_score_topk_f32's, which the tests above pin against the oracle; a ragged last panel, a ragged
+    last tile, users without a held-out item, masked held-out items, repeated train entries."""
+    from deeprec_amd import kernels as K
+    rng = np.random.default_rng(k + kind)
+    Nu, Ni = 128 * 128 + 77, 64 * 9 + 21
+    U = (rng.standard_normal((Nu, k)) * 0.2).astype(np.float32)
+    I = (rng.standard_normal((Ni, k)) * 0.2).astype(np.float32)
+    I[Ni // 3] = I[Ni // 5]                                       # tied items
+    ntr = 12
+    train = np.sort(rng.integers(0, Ni, (Nu, ntr)), 1).astype(np.int32)      # sorted, entries may repeat
+    tp = (np.arange(Nu + 1) * ntr).astype(np.int32)
+    has = rng.random(Nu) < 0.9
+    tgt = rng.integers(0, Ni, Nu).astype(np.int32)
+    tgt[::11] = train[::11, 3]                                    # masked held-out items -> -1
+    tgt[5::13] = Ni // 3
+    gp = np.concatenate(([0], np.cumsum(has))).astype(np.int32)
+    gi = tgt[has]
+    kw = {}
+    if kind == 2:
+        kw = dict(U2=T((rng.standard_normal((Nu, k)) * 0.2).astype(np.float32), dev),
+                  I2=T((rng.standard_normal((Ni, k)) * 0.2).astype(np.float32), dev), alpha=0.2)
+    tr, tg = (T(tp, dev), T(train.reshape(-1), dev)), (T(gp, dev), T(gi, dev))
+    want = K.score_topk(T(U, dev), T(I, dev), 1, score_kind=kind, train=tr, targets=tg, **kw)[2]
+    for _ in range(2):
+        assert torch.equal(K.score_rank(T(U, dev), T(I, dev), tg, score_kind=kind, train=tr, **kw), want)
+    assert int((want < 0).sum()) > 100 and int((want > 0).sum()) > 1000
 
 
 @pytest.mark.parametrize("kind", [1, 2])
@@ -601,6 +641,12 @@ def test_score_topk_distances(dev, kind):
                                   targets=(T(gp, dev), T(gi, dev)), **kw)
     scores = co.score_matrix(U, I, kind, U2 if kind == 2 else None, I2 if kind == 2 else None, 0.2)
     _check_selection(scores, train, tgt, K_, N(idx), N(val), N(rank))
+    assert torch.equal(K.score_rank(T(U, dev), T(I, dev), (T(gp, dev), T(gi, dev)), score_kind=kind,
+                                    train=(T(tp, dev), T(ti, dev)), **kw), rank)     # several held-out items: general kernel
+    one = [t[:1] for t in tgt]                                                   # one each: the rank-only kernel (k = 100 / 300)
+    op, oi = _csr(one)
+    r1 = N(K.score_rank(T(U, dev), T(I, dev), (T(op, dev), T(oi, dev)), score_kind=kind, train=(T(tp, dev), T(ti, dev)), **kw))
+    _check_selection(scores, train, one, K_, N(idx), N(val), r1)
     sm = N(K.score_matrix(T(U, dev), T(I, dev), score_kind=kind, **kw))
     assert np.array_equal(sm.view(np.uint32), scores.view(np.uint32))
     # and the canonical score is within 1e-5 relative of the reference's direct formula
