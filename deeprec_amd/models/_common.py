@@ -650,14 +650,24 @@ def attn_seq(v, timing, W):
     return _AttnSeq.apply(v, timing, W)
 
 
+def _check_unit_grad(gl):
+    import os
+    if os.environ.get("DR_CHECK_GL") and float(gl) != 1.0:
+        raise RuntimeError("fused loss: backward() was called with gradient %r, but the recorded table rows are unscaled; "
+                           "pass the scale into the loss kernel instead" % float(gl))
+
+
 class _SeqDistLoss(torch.autograd.Function):
     """Two-distance interaction + pairwise loss fused with the item / user lookups (dr_seq_dist_loss_f32): the
     forward launches ONE kernel that also produces every gradient; the backward records the gradient rows of the
     tables X, Q, P for the segment update and hands d loss / d o back to autograd.
 
     The result must be the tensor backward() is called on (as the reference's `minimize(self.loss)` does,
-    AttRec.py:110, PRME.py:98): the recorded rows are d loss / d row as they stand -- the incoming gradient (1) is not
-    read back from the device, so that the step stays free of host synchronisation and replays as a hipGraph."""
+    AttRec.py:110, PRME.py:98): the recorded TABLE rows are d loss / d row as they stand -- the incoming gradient (1) is
+    not read back from the device, so that the step stays free of host synchronisation and replays as a hipGraph.  The
+    gradient handed back to autograd IS scaled by the incoming one (on the device), and DR_CHECK_GL=1 makes backward()
+    verify that the incoming gradient is 1 (a host read-back: debugging only) -- a caller that wants a scaled loss
+    passes the scale INTO the kernel (seq_dot_loss's `scale`) instead of multiplying the result."""
 
     @staticmethod
     def forward(ctx, o, tP, tX, tQ, users, tgt, neg, alpha, kind, margin, items):
@@ -677,7 +687,8 @@ class _SeqDistLoss(torch.autograd.Function):
         tX.pending.append((items, gX.reshape(-1, k)))
         tQ.pending.append((items, gQ.reshape(-1, k)))
         tP.pending.append((users, gp))
-        return (go,) + (None,) * 10
+        _check_unit_grad(gl)
+        return (go * gl,) + (None,) * 10
 
 
 def seq_dist_loss(o, tP, tX, tQ, users, tgt, neg, alpha, kind, margin=0.5, items=None):
@@ -704,7 +715,8 @@ class _SeqDotLoss(torch.autograd.Function):
         tW, tb = ctx.tabs
         tW.pending.append((ctx.items, gW.reshape(-1, gW.shape[2])))
         tb.pending.append((ctx.items, gb.reshape(-1)))
-        return (gx, None, None, None, None, None, None)
+        _check_unit_grad(gl)
+        return (gx * gl, None, None, None, None, None, None)
 
 
 def seq_dot_loss(x, tW, tb, tgt, neg, scale=1.0, items=None):

@@ -108,13 +108,14 @@ class Caser(SeqBase):
         print("Caser.")
 
     def build_network(self, L, num_T, n_h=16, n_v=4, num_factor=150, num_neg=2, init=None, lazy_v=True,
-                      neg_alignment="intended"):
+                      neg_alignment="reference"):
         """neg_alignment: Caser.train draws its negatives with _get_neg_items(self.users.squeeze(), ...) (Caser.py:243) --
         row r of the negatives is drawn from the pool of the r-th user in STORAGE order, but is fed next to the r-th user
         of the PERMUTED epoch (Caser.py:237-254), so a sample trains against negatives of an unrelated user (which may
-        be its own user's positives).  "intended" (default) draws row r for the user it is fed with; "reference"
-        reproduces the reference's misalignment draw for draw.  Either way the pool is the
-        user's whole-train-row complement neg_items[u] (Caser.py:302-319), not the targets-only pool of AttRec / PRME."""
+        be its own user's positives).  "reference" (default: a drop-in reproduces the reference's sampling stream and
+        loss curve, draw for draw) keeps that; "intended" draws row r for the user it is fed with (DESIGN.md section 8,
+        D9).  Either way the pool is the user's whole-train-row complement neg_items[u] (Caser.py:302-319), not the
+        targets-only pool of AttRec / PRME."""
         if neg_alignment not in ("intended", "reference"):
             raise ValueError("neg_alignment must be 'intended' or 'reference'")
         self.neg_alignment = neg_alignment

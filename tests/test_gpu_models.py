@@ -890,7 +890,7 @@ def test_seq_models_negative_pools_and_device_samplers(dev, tmp_path):
         assert np.array_equal(negs, want[:len(negs)].astype(np.int32)), align
     # device samplers: same pools, no host loop
     for cls, kw in ((AttRec, dict(num_factor=8)), (PRME, dict(num_factor=8)),
-                    (Caser, dict(num_factor=8, n_h=2, n_v=1, num_neg=1))):
+                    (Caser, dict(num_factor=8, n_h=2, n_v=1, num_neg=1, neg_alignment="intended"))):
         m, got = run(cls, kw, "device")
         assert len(got) >= 2
         for u_, t_, n_ in got:
