@@ -31,6 +31,11 @@ trainer routes batch t+1 on a second stream / second communicator while batch t 
 (`ShardedBpr.step(..., next_batch=...)`); the host synchronisation of a route then waits on short id kernels only.
 Every per-step buffer (three route workspaces, id lists, exchange buffers, pinned split sizes) is allocated once.
 
+Models built from lookups under autograd (AttRec, Caser) are data-parallel over their batch with the same row-sharded
+tables: `StepRoute` makes ONE route for all lookups of a step (id all-gather; route keys + two bucket orders; one host
+synchronisation; one all-to-all with the rows of every (table, list) pair, one with every gradient row going back),
+`RowRoute` / `fetch_rows` remain for single ad-hoc lookups (evaluation).
+
 `ops` is the kernel namespace (default: deeprec_amd.kernels = the HIP library).  The package ships no
 other implementation; tests inject an oracle-backed namespace to exercise the exchange logic on CPU
 with gloo.
