@@ -582,6 +582,52 @@ __device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* areg, const
 #undef DR_PB
 }
 
+// mfma_chunk with the A operands in LDS too (second half of a k > 128 user panel, stored like an item tile: row =
+// the lane's user, same k permutation): pa / pax = sP + row * LDP + 4 * h and the same with the halves swapped.
+template <int NG>
+__device__ __forceinline__ void mfma_chunk_pl(f32x16& acc, const float* __restrict__ pa, const float* __restrict__ pax,
+                                              const float* __restrict__ pb, const float* __restrict__ pbx, int ng) {
+    float4 b[2][2], av[2][2];
+#define DR_PB(g_) ((((g_) >> 1) & 1) ? pbx : pb)
+#define DR_PA(g_) ((((g_) >> 1) & 1) ? pax : pa)
+    b[0][0] = *reinterpret_cast<const float4*>(pb);
+    b[0][1] = *reinterpret_cast<const float4*>(pb + 8);
+    av[0][0] = *reinterpret_cast<const float4*>(pa);
+    av[0][1] = *reinterpret_cast<const float4*>(pa + 8);
+#define DR_MFMA_GROUP(gq)                                                                                          \
+    {                                                                                                              \
+        if ((gq) + 1 < NG) {                                                                                       \
+            b[((gq) + 1) & 1][0] = *reinterpret_cast<const float4*>(DR_PB((gq) + 1) + ((gq) + 1) * 16);            \
+            b[((gq) + 1) & 1][1] = *reinterpret_cast<const float4*>(DR_PB((gq) + 1) + ((gq) + 1) * 16 + 8);        \
+            av[((gq) + 1) & 1][0] = *reinterpret_cast<const float4*>(DR_PA((gq) + 1) + ((gq) + 1) * 16);           \
+            av[((gq) + 1) & 1][1] = *reinterpret_cast<const float4*>(DR_PA((gq) + 1) + ((gq) + 1) * 16 + 8);       \
+        }                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        const float4 x = b[(gq) & 1][0], y = b[(gq) & 1][1];                                                       \
+        const float4 p = av[(gq) & 1][0], q = av[(gq) & 1][1];                                                     \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, x.x, acc, 0, 0, 0);                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, x.y, acc, 0, 0, 0);                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, x.z, acc, 0, 0, 0);                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, x.w, acc, 0, 0, 0);                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, y.x, acc, 0, 0, 0);                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, y.y, acc, 0, 0, 0);                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, y.z, acc, 0, 0, 0);                                        \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, y.w, acc, 0, 0, 0);                                        \
+    }
+    if (ng == NG) {
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) DR_MFMA_GROUP(gq)
+    } else {
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq < ng) DR_MFMA_GROUP(gq)  // uniform
+        }
+    }
+#undef DR_MFMA_GROUP
+#undef DR_PB
+#undef DR_PA
+}
+
 template <int KS>
 __device__ __forceinline__ void load_areg(float (&areg)[KS], const ScoreArgs& a, int64_t u0, int wu, int lane) {
     const int64_t urow = u0 + wu * 32 + (lane & 31);
@@ -1086,9 +1132,13 @@ __device__ __forceinline__ void prefetch_rows(float (&pre)[N], const float* __re
     }
 }
 
-template <int KS, bool VEC, bool AFFINE, int WU, bool BAND>
+// PL (k in (128, 256], 128-user panels): k-steps 0..63 of the user panel in registers, 64..127 in LDS beside the item
+// tiles (stored like an item tile), so that 8 waves per CU fit their registers without spilling to memory.
+template <int KS, bool VEC, bool AFFINE, int WU, bool BAND, bool PL = false>
 __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 64)) ? 2 : 1) void score_rank_kernel(ScoreArgs a) {
+    static_assert(!PL || (KS == 128 && WU == 4 && !BAND), "panel-in-LDS form: k > 128, 128-user panels");
     constexpr int NT = 128 * WU, TUK = 32 * WU;     // WU waves of 32 users x 2 waves of 32 items
+    constexpr int KR = PL ? KS / 2 : KS;            // k-steps of the user panel held in registers
     using G = Geo<KS, VEC, NT>;
     constexpr int NCH = (2 * KS + KC - 1) / KC;      // k-chunks per tile: 1 (k <= 128) or 2 (this instantiation: k > 128)
     constexpr int JPC = KS < KC / 2 ? KS : KC / 2;
@@ -1096,7 +1146,8 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
     if (*a.mode_flag != 0) return;  // some user has several held-out items: score_kernel handles this call
     extern __shared__ __align__(16) float smem[];
     float* sI = smem;               // [2][TI][LDP], k-permuted (see LDP); with two chunks buffer c always holds chunk c
-    float* base = smem + 2 * BUF;
+    float* sP = smem + 2 * BUF;     // PL: [TUK][LDP], k = KC.. of the panel's users, same permutation
+    float* base = smem + 2 * BUF + (PL ? TUK * LDP : 0);
     float* tsc = base;
     int* tidl = reinterpret_cast<int*>(base + TUK);
     int* tcnt = reinterpret_cast<int*>(base + 2 * TUK);
@@ -1118,9 +1169,18 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
     if (t_end > a.ntiles) t_end = a.ntiles;
     const int k = a.k;
 
-    float areg[KS];
-    load_areg<KS>(areg, a, u0, wu, lane);
+    float areg[KR];
+    load_areg<KR>(areg, a, u0, wu, lane);
     for (int e = tid; e < 2 * BUF; e += NT) sI[e] = 0.0f;   // columns that no chunk store touches read as zero
+    if (PL) {
+        for (int e = tid; e < TUK * KC; e += NT) {
+            const int row = e / KC, kk = e % KC;
+            const int64_t u = u0 + row;
+            sP[row * LDP + kpos(kk)] = (u < a.Nu && KC + kk < k) ? a.U[u * k + KC + kk] : 0.0f;
+        }
+    }
+    const float* pa = sP + (wu * 32 + (lane & 31)) * LDP + 4 * (lane >> 5);
+    const float* pax = sP + (wu * 32 + (lane & 31)) * LDP + 4 * (1 - (lane >> 5));
     if (tid < TUK) {
         const int64_t u = u0 + tid;
         tcnt[tid] = 0;
@@ -1218,7 +1278,8 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
                 else prefetch_chunk<KS, VEC, G::NPRE, NT>(pre, a.I, i0 + 2 * TI, a.Ni, k, 0, r0, gc0);
             }
             if (AFFINE && c == NCH - 1 && t + 1 < t_end) ia_next = load_iadd(a, i0 + TI + mycol);
-            mfma_chunk<JPC / 8>(acc, areg + c * (KC / 2), pb + cur * BUF, pbx + cur * BUF, c == 0 ? ng0 : ng1);
+            if (PL && c == 1) mfma_chunk_pl<JPC / 8>(acc, pa, pax, pb + cur * BUF, pbx + cur * BUF, ng1);
+            else mfma_chunk<JPC / 8>(acc, areg + (PL ? 0 : c * (KC / 2)), pb + cur * BUF, pbx + cur * BUF, c == 0 ? ng0 : ng1);
             if (c == NCH - 1) {
                 if (AFFINE) {
                     const float cd = a.cdot;
@@ -1325,8 +1386,10 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __syncthreads();
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
-                mfma_chunk<JPC / 8>(acc, areg + c * (KC / 2), pb + c * BUF, pbx + c * BUF, c == 0 ? ng0 : ng1);
+            for (int c = 0; c < NCH; ++c) {
+                if (PL && c == 1) mfma_chunk_pl<JPC / 8>(acc, pa, pax, pb + c * BUF, pbx + c * BUF, ng1);
+                else mfma_chunk<JPC / 8>(acc, areg + (PL ? 0 : c * (KC / 2)), pb + c * BUF, pbx + c * BUF, c == 0 ? ng0 : ng1);
+            }
             const int it = mitem[mycol], rw = mrow[mycol];
             if (it >= 0) {
                 const float ia2 = AFFINE ? load_iadd(a, it) : -0.0f;
@@ -1646,22 +1709,22 @@ static int launch_score_t1(const ScoreArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // grid.y = item splits (as for the other kernels); grid.x is computed here from the kernel's own panel height
-template <int KS, bool VEC, bool AFFINE, int WU, bool BAND>
+template <int KS, bool VEC, bool AFFINE, int WU, bool BAND, bool PL = false>
 static int launch_score_rank_kaw(const ScoreArgs& a, unsigned splits, hipStream_t st) {
-    const size_t smem = ((size_t)2 * TI * LDP + 6 * 32 * WU + 8 + 2 * TI) * 4;
+    const size_t smem = ((size_t)2 * TI * LDP + (PL ? (size_t)32 * WU * LDP : 0) + 6 * 32 * WU + 8 + 2 * TI) * 4;
     const int64_t panels = (a.Nu + 32 * WU - 1) / (32 * WU);
-    DR_HIP(hipFuncSetAttribute((const void*)score_rank_kernel<KS, VEC, AFFINE, WU, BAND>,
+    DR_HIP(hipFuncSetAttribute((const void*)score_rank_kernel<KS, VEC, AFFINE, WU, BAND, PL>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    DR_LAUNCH_NAMED("score_rank_kernel", (score_rank_kernel<KS, VEC, AFFINE, WU, BAND>), dim3((unsigned)panels, splits),
+    DR_LAUNCH_NAMED("score_rank_kernel", (score_rank_kernel<KS, VEC, AFFINE, WU, BAND, PL>), dim3((unsigned)panels, splits),
                     dim3(128 * WU), smem, st, a);
     DR_CHECK_LAUNCH("score_rank_kernel");
     return DR_OK;
 }
-template <int KS, bool VEC, int WU, bool BAND>
+template <int KS, bool VEC, int WU, bool BAND, bool PL = false>
 static int launch_score_rank_k(const ScoreArgs& a, unsigned splits, hipStream_t st) {
     const bool affine = a.uadd || a.iadd || a.cdot != 1.0f;
-    return affine ? launch_score_rank_kaw<KS, VEC, true, WU, BAND>(a, splits, st)
-                  : launch_score_rank_kaw<KS, VEC, false, WU, BAND>(a, splits, st);
+    return affine ? launch_score_rank_kaw<KS, VEC, true, WU, BAND, PL>(a, splits, st)
+                  : launch_score_rank_kaw<KS, VEC, false, WU, BAND, PL>(a, splits, st);
 }
 template <bool BAND>
 static int launch_score_rank(const ScoreArgs& a, unsigned splits, hipStream_t st) {   // k <= 256
@@ -1675,6 +1738,7 @@ static int launch_score_rank(const ScoreArgs& a, unsigned splits, hipStream_t st
         if (tall) return launch_score_rank_k<64, true, 4, false>(a, splits, st);
         return vec ? launch_score_rank_k<64, true, 2, BAND>(a, splits, st) : launch_score_rank_k<64, false, 2, BAND>(a, splits, st);
     }
+    if (tall) return launch_score_rank_k<128, true, 4, false, true>(a, splits, st);   // second half of the panel in LDS
     return vec ? launch_score_rank_k<128, true, 2, BAND>(a, splits, st) : launch_score_rank_k<128, false, 2, BAND>(a, splits, st);
 }
 

@@ -592,10 +592,10 @@ def test_score_kernel_instantiations_repeatable_and_exact(dev, k, kind, ntgt):
         assert np.array_equal(r, want)
 
 
-@pytest.mark.parametrize("k,kind", [(64, 0), (128, 1), (40, 2)])
+@pytest.mark.parametrize("k,kind", [(64, 0), (128, 1), (40, 2), (256, 0), (136, 0), (200, 1), (72, 2), (128, 2)])
 def test_score_rank_tall_panels(dev, k, kind):
-    """dr_score_rank_f32 with >= 16 384 users and k <= 128: the rank-only kernel runs 128-user panels (one workgroup of
-    8 waves); ranks equal dr_score_topk_f32's, which the tests above pin against the oracle; a ragged last panel, a ragged
+    """dr_score_rank_f32 with >= 16 384 users: the rank-only kernel runs 128-user panels (one workgroup of 8 waves; for
+    128 < k_eff <= 256 with the second half of the user panel in LDS: full, 8-wide and ragged second chunks); ranks equal dr_score_topk_f32's, which the tests above pin against the oracle; a ragged last panel, a ragged
     last tile, users without a held-out item, masked held-out items, repeated train entries."""
     from deeprec_amd import kernels as K
     rng = np.random.default_rng(k + kind)
