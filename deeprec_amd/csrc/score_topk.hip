@@ -1107,6 +1107,10 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
 // with two 64-user workgroups per CU) once there are enough users to fill the chip that way, 128 < k <= 256 stays at 64
 // users (the 128-register user panel + 8 waves per CU leaves 256 registers per wave: 40-60 spill to memory, 0.46
 // against 0.58).
+#ifndef DR_RK_PIPE
+#define DR_RK_PIPE 1   // the epilogue of tile t runs behind the MFMA chain of tile t + 1 (second accumulator)
+#endif
+// (requesting a stage's first B operands right behind the barrier, ahead of the stage's stores and loads: no change, 38.0 ms)
 #ifndef RK_CNT
 #define RK_CNT 1   // 1: per-lane vector counters; 0: row counters in scalar registers (ballot + popcount: the 32 counters do
                    // not fit the scalar file beside the kernel's other state -- 80 v_readlane / v_writelane per two tiles)
@@ -1139,6 +1143,12 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
     static_assert(!PL || (KS == 128 && WU == 4 && !BAND), "panel-in-LDS form: k > 128, 128-user panels");
     constexpr int NT = 128 * WU, TUK = 32 * WU;     // WU waves of 32 users x 2 waves of 32 items
     constexpr int KR = PL ? KS / 2 : KS;            // k-steps of the user panel held in registers
+    // PIPE: the epilogue of tile t (compare / count) runs after the MFMA chain of tile t + 1 has been issued, on a second
+    // accumulator, with the rows' thresholds (and affine terms) read from LDS: its vector instructions and LDS reads
+    // overlap that chain instead of waiting for the pipeline to drain
+    // (not where the second accumulator would spill to memory inside the stream: the BAND forms, the panel-in-LDS form and
+    // 64-user panels with k > 64 keep the epilogue behind its own chain)
+    constexpr bool PIPE = DR_RK_PIPE && !BAND && !PL && (WU == 4 || KS == 32);
     using G = Geo<KS, VEC, NT>;
     constexpr int NCH = (2 * KS + KC - 1) / KC;      // k-chunks per tile: 1 (k <= 128) or 2 (this instantiation: k > 128)
     constexpr int JPC = KS < KC / 2 ? KS : KC / 2;
@@ -1157,6 +1167,7 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
     float* tlo = reinterpret_cast<float*>(mrow + TI);      // BAND: lower end of the held-out item's band
     int* tslot = reinterpret_cast<int*>(tlo + TUK);        // BAND: its slot in the target CSR
     int* wmax = tslot + TUK;                               // BAND: widest band of the panel (float bits)
+    float* tua = reinterpret_cast<float*>(wmax + 4);       // PIPE: the rows' affine terms
     if (threadIdx.x == 0) *wmax = 0;
     __syncthreads();
 
@@ -1205,7 +1216,8 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
     }
     if (tid <= TUK) tptr[tid] = a.train_ptr ? a.train_ptr[(u0 + tid < a.Nu) ? u0 + tid : a.Nu] : 0;
     float ua[16];
-    if (AFFINE) load_uadd(ua, a, u0, wu, lane);
+    if (AFFINE && !PIPE) load_uadd(ua, a, u0, wu, lane);
+    if (AFFINE && PIPE && tid < TUK) tua[tid] = (a.uadd && u0 + tid < a.Nu) ? a.uadd[u0 + tid] : -0.0f;
     const int mycol = wi * 32 + (lane & 31);
     const int rbase = wu * 32 + 4 * (lane >> 5);   // row of accumulator element r = rbase + (r&3) + 8*(r>>2)
 
@@ -1222,8 +1234,10 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
 
     __syncthreads();
     float stR[16];
+    if (!PIPE) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) stR[r] = tsc[rbase + (r & 3) + 8 * (r >> 2)];
+        for (int r = 0; r < 16; ++r) stR[r] = tsc[rbase + (r & 3) + 8 * (r >> 2)];
+    }
     // BAND: the stream only asks "within the panel's WIDEST band below hi?" (one scalar, no second threshold per row in
     // registers; padded so that rounding of the sum cannot lose a score on a band's lower end); the row's own lower end is
     // read from LDS on the rare path
@@ -1256,10 +1270,78 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __syncthreads();
 
-    int s = 0;
-    for (int t = t_begin; t < t_end; ++t) {
+    // The epilogue of tile t (compare / count) runs after the MFMA chain of tile t + 1 has been issued, on a second
+    // accumulator: its vector instructions overlap that chain instead of waiting for the pipeline to drain (DR_RK_PIPE 0:
+    // the epilogue follows its own chain).
+    auto epilogue = [&](f32x16& acc, int t, float ia) {
         const int64_t i0 = (int64_t)t * TI;
-        f32x16 acc;
+        float st[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (PIPE) {
+                const float4 v = *reinterpret_cast<const float4*>(tsc + rbase + 8 * q);
+                st[4 * q] = v.x; st[4 * q + 1] = v.y; st[4 * q + 2] = v.z; st[4 * q + 3] = v.w;
+            } else {
+                st[4 * q] = stR[4 * q]; st[4 * q + 1] = stR[4 * q + 1]; st[4 * q + 2] = stR[4 * q + 2]; st[4 * q + 3] = stR[4 * q + 3];
+            }
+        }
+        if (AFFINE) {
+            const float cd = a.cdot;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 w;
+                if (PIPE) w = *reinterpret_cast<const float4*>(tua + rbase + 8 * q);
+                else w = make_float4(ua[4 * q], ua[4 * q + 1], ua[4 * q + 2], ua[4 * q + 3]);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sc = cd * acc[4 * q + e];
+                    sc = sc + wv[e];
+                    acc[4 * q + e] = sc + ia;
+                }
+            }
+        }
+        if (t == a.ntiles - 1 && ((int)a.Ni & (TI - 1)) != 0 && mycol >= ((int)a.Ni & (TI - 1))) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = -INFINITY;   // columns beyond the catalog beat nothing
+        }
+        unsigned long long eq = 0ull;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#if RK_CNT == 0
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(acc[r] > st[r]);
+            cA[r] += __builtin_popcount((unsigned)m);
+            cB[r] += __builtin_popcount((unsigned)(m >> 32));
+#else
+            cA[r] += (acc[r] > st[r]) ? 1 : 0;
+#endif
+            if (BAND) eq |= __builtin_amdgcn_ballot_w64(acc[r] <= st[r] && acc[r] + wpad >= st[r]);
+            else eq |= __builtin_amdgcn_ballot_w64(acc[r] == st[r]);
+        }
+        if (eq) {   // a tie with the held-out item (or the item itself): decided by item id; BAND: inside the band
+            const int item = (int)i0 + mycol;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (BAND) {
+                    const bool near = acc[r] <= st[r] && acc[r] + wpad >= st[r];
+                    if (__builtin_amdgcn_ballot_w64(near) == 0ull) continue;      // uniform: nothing for this r
+                    if (near && acc[r] >= tlo[row]) {
+                        const int ct = tidl[row];
+                        if (ct >= 0 && item != ct) band_append(row, item);
+                    }
+                } else if (acc[r] == st[r]) {
+                    const int ct = tidl[row];
+                    if (ct >= 0 && item < ct) atomicAdd(&tcnt[row], 1);
+                }
+            }
+        }
+    };
+    int s = 0;
+    float ia_prev = -0.0f;
+    // one tile: its chunks' stores / prefetches / MFMA chains into `acc`; `accp` = the previous tile's scores
+    auto tile = [&](int t, f32x16& acc, f32x16& accp, bool havep) {
+        const int64_t i0 = (int64_t)t * TI;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         const float ia = ia_next;
@@ -1280,55 +1362,35 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
             if (AFFINE && c == NCH - 1 && t + 1 < t_end) ia_next = load_iadd(a, i0 + TI + mycol);
             if (PL && c == 1) mfma_chunk_pl<JPC / 8>(acc, pa, pax, pb + cur * BUF, pbx + cur * BUF, ng1);
             else mfma_chunk<JPC / 8>(acc, areg + (PL ? 0 : c * (KC / 2)), pb + cur * BUF, pbx + cur * BUF, c == 0 ? ng0 : ng1);
-            if (c == NCH - 1) {
-                if (AFFINE) {
-                    const float cd = a.cdot;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float sc = cd * acc[r];
-                        sc = sc + ua[r];
-                        acc[r] = sc + ia;
-                    }
-                }
-                if (t == a.ntiles - 1 && ((int)a.Ni & (TI - 1)) != 0 && mycol >= ((int)a.Ni & (TI - 1))) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = -INFINITY;   // columns beyond the catalog beat nothing
-                }
-                unsigned long long eq = 0ull;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-#if RK_CNT == 0
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(acc[r] > stR[r]);
-                    cA[r] += __builtin_popcount((unsigned)m);
-                    cB[r] += __builtin_popcount((unsigned)(m >> 32));
-#else
-                    cA[r] += (acc[r] > stR[r]) ? 1 : 0;
-#endif
-                    if (BAND) eq |= __builtin_amdgcn_ballot_w64(acc[r] <= stR[r] && acc[r] + wpad >= stR[r]);
-                    else eq |= __builtin_amdgcn_ballot_w64(acc[r] == stR[r]);
-                }
-                if (eq) {   // a tie with the held-out item (or the item itself): decided by item id; BAND: inside the band
-                    const int item = (int)i0 + mycol;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rbase + (r & 3) + 8 * (r >> 2);
-                        if (BAND) {
-                            const bool near = acc[r] <= stR[r] && acc[r] + wpad >= stR[r];
-                            if (__builtin_amdgcn_ballot_w64(near) == 0ull) continue;      // uniform: nothing for this r
-                            if (near && acc[r] >= tlo[row]) {
-                                const int ct = tidl[row];
-                                if (ct >= 0 && item != ct) band_append(row, item);
-                            }
-                        } else if (acc[r] == stR[r]) {
-                            const int ct = tidl[row];
-                            if (ct >= 0 && item < ct) atomicAdd(&tcnt[row], 1);
-                        }
-                    }
-                }
-            }
+            if (PIPE) {
+                if (c == 0 && havep) epilogue(accp, t - 1, ia_prev);
+            } else if (c == NCH - 1) epilogue(acc, t, ia);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __syncthreads();
         }
+        ia_prev = ia;
+    };
+    if (!PIPE) {
+        f32x16 acc;
+        for (int t = t_begin; t < t_end; ++t) tile(t, acc, acc, false);
+    } else {
+        f32x16 acc0, acc1;
+        int t = t_begin;
+        for (; t + 1 < t_end; t += 2) {
+            tile(t, acc0, acc1, t > t_begin);
+            tile(t + 1, acc1, acc0, true);
+        }
+        if (t < t_end) {
+            tile(t, acc0, acc1, t > t_begin);
+            if (PIPE) epilogue(acc0, t, ia_prev);
+        } else if (t_end > t_begin) {
+            if (PIPE) epilogue(acc1, t_end - 1, ia_prev);
+        }
+    }
+    if (PIPE) {   // for the correction tiles below
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stR[r] = tsc[rbase + (r & 3) + 8 * (r >> 2)];
+        if (AFFINE) load_uadd(ua, a, u0, wu, lane);
     }
 #if RK_CNT == 0
     if (lane == 0) {
@@ -1711,7 +1773,7 @@ static int launch_score_t1(const ScoreArgs& a, dim3 grid, hipStream_t st) {
 // grid.y = item splits (as for the other kernels); grid.x is computed here from the kernel's own panel height
 template <int KS, bool VEC, bool AFFINE, int WU, bool BAND, bool PL = false>
 static int launch_score_rank_kaw(const ScoreArgs& a, unsigned splits, hipStream_t st) {
-    const size_t smem = ((size_t)2 * TI * LDP + (PL ? (size_t)32 * WU * LDP : 0) + 6 * 32 * WU + 8 + 2 * TI) * 4;
+    const size_t smem = ((size_t)2 * TI * LDP + (PL ? (size_t)32 * WU * LDP : 0) + 7 * 32 * WU + 12 + 2 * TI) * 4;
     const int64_t panels = (a.Nu + 32 * WU - 1) / (32 * WU);
     DR_HIP(hipFuncSetAttribute((const void*)score_rank_kernel<KS, VEC, AFFINE, WU, BAND, PL>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
