@@ -522,6 +522,15 @@ __device__ __forceinline__ void prefetch_chunk(float (&pre)[N], const float* __r
     }
 }
 
+// The values a prefetch left in `pre` become opaque here: the even / odd shuffle of store_chunk (and the s_waitcnt vmcnt
+// it needs) cannot be hoisted from the store to right behind the loads -- where the compiler otherwise puts it, so that
+// the wave waited for the tile it had just requested BEFORE its MFMA chain instead of after it.
+template <int N>
+__device__ __forceinline__ void pin_prefetched(float (&pre)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(pre[i]));
+}
+
 // d = sI + r0 * LDP + (VEC ? g * 8 + 4 * ((g >> 2) & 1) : kpos(g)): where the even k of the thread's group go (VEC: the
 // odd k go to the other half of the group, d ^ 16 bytes)
 template <int KS, bool VEC, int N, int NT = 256>
@@ -1111,6 +1120,9 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
 #define DR_RK_PIPE 1   // the epilogue of tile t runs behind the MFMA chain of tile t + 1 (second accumulator)
 #endif
 // (requesting a stage's first B operands right behind the barrier, ahead of the stage's stores and loads: no change, 38.0 ms)
+#ifndef DR_RK_PIN
+#define DR_RK_PIN 1
+#endif
 #ifndef RK_CNT
 #define RK_CNT 1   // 1: per-lane vector counters; 0: row counters in scalar registers (ballot + popcount: the 32 counters do
                    // not fit the scalar file beside the kernel's other state -- 80 v_readlane / v_writelane per two tiles)
@@ -1351,6 +1363,7 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
             const int oth = cur ^ 1;
             // stage s + 1 (in registers since the previous stage's MFMA chain) -> the other buffer: its last readers
             // passed the barrier that ended stage s - 1
+            if (DR_RK_PIN) pin_prefetched(pre);
             if (s + 1 < nst) {
                 const bool lv = (NCH > 1 && c == 0) ? live1 : live0;
                 if (lv) store_chunk<KS, VEC, G::NPRE, NT>(dst + oth * BUF, dst_odd + oth * BUF, pre);

@@ -22,7 +22,8 @@ def main():
     tg = torch.randint(0, ni, (nu,), device=dev, generator=g).to(torch.int32)
     gp = torch.arange(nu + 1, device=dev).to(torch.int32)
     for _ in range(int(os.environ.get("REPS", "3"))):
-        K.score_topk(U, I, 10, train=(tp, tr), targets=(gp, tg))
+        K.score_topk(U, I, 10, train=(tp, tr), targets=(gp, tg))      # score_kernel_t1: top-10 list + ranks
+        K.score_rank(U, I, (gp, tg), train=(tp, tr))                  # score_rank_kernel: ranks only (the evaluators' call)
     torch.cuda.synchronize()
     print("ok")
 
