@@ -12,6 +12,8 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format cs
 cd $R
 python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write r03_pmc_traffic.json > gpurun_out/pmc_traffic.log 2>&1
 cp profiles/r03_pmc_traffic.json gpurun_out/
+(bash tools/pmc_score.sh) && python tools/pmc_score_summary.py gpurun_out/pmc_score1 gpurun_out/pmc_score2 r03_pmc_score_kernel.json > gpurun_out/pmc_score_summary.log 2>&1
+cp profiles/r03_pmc_score_kernel.json gpurun_out/
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_r3.json 2> gpurun_out/bench_r3.err || { tail -20 gpurun_out/bench_r3.err; exit 1; }
 timeout -k 10 300 python bench.py --sharded --steps 20 --warmup 5 --no-cpu-baseline 2> gpurun_out/bench_r3_sharded.err | tail -1 > gpurun_out/bench_r3_sharded.json
 cd /tmp
