@@ -1181,6 +1181,7 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
     int* wmax = tslot + TUK;                               // BAND: widest band of the panel (float bits)
     float* tua = reinterpret_cast<float*>(wmax + 4);       // PIPE: the rows' affine terms
     if (threadIdx.x == 0) *wmax = 0;
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // no LDS store / atomic of this wave in flight at a barrier (make check)
     __syncthreads();
 
     const int tid = threadIdx.x;
@@ -1244,6 +1245,7 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
     const float* pbx = sI + mycol * LDP + 4 * (1 - (lane >> 5));
     const int ng0 = (kc_first + 15) >> 4, ng1 = NCH > 1 ? ((k - KC + 15) >> 4) : 0;
 
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // no LDS store / atomic of this wave in flight at a barrier (make check)
     __syncthreads();
     float stR[16];
     if (!PIPE) {
@@ -1426,6 +1428,7 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
         const int64_t hi64 = (int64_t)t_end * TI < a.Ni ? (int64_t)t_end * TI : a.Ni;
         const int hi_item = (int)hi64;
         for (int e0 = E0; e0 < E1; e0 += TI) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // no LDS store / atomic of this wave in flight at a barrier (make check)
             __syncthreads();                   // the previous tile's readers of mitem / mrow / sI are done
             int item = -1;
             if (tid < TI) {
@@ -1448,6 +1451,7 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
                 mitem[tid] = item;
                 mrow[tid] = row;
             }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
             if (!__syncthreads_or(item >= 0)) continue;
             f32x16 acc;
 #pragma unroll
@@ -1489,6 +1493,7 @@ __global__ __launch_bounds__(128 * WU, (WU == 2 && KS < 128 && !(BAND && KS >= 6
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // no LDS store / atomic of this wave in flight at a barrier (make check)
     __syncthreads();
     if (a.tgt_ptr && tid < TUK && u0 + tid < a.Nu && tcnt[tid] != 0 && tidl[tid] >= 0)
         atomicAdd(a.tgt_rank + a.tgt_ptr[u0 + tid], tcnt[tid]);

@@ -54,13 +54,14 @@ def test_argument_errors_without_gpu():
 
 
 def test_isa_no_barrier_with_lds_store_in_flight():
-    """`make check` (deeprec_amd/csrc/Makefile): the device assembly of every scoring-kernel instantiation has an
-    lgkmcnt(0) wait on every path between an LDS store / atomic and the next s_barrier (round 2's lost top-K entries),
-    and the checker flags the hand-written negative fixture.  Needs hipcc only (cross-compiles without a GPU)."""
+    """`make check` (deeprec_amd/csrc/Makefile): the device assembly of every kernel of the library that has a workgroup
+    barrier has an lgkmcnt(0) wait on every path between an LDS store / atomic and the next s_barrier (round 2's lost
+    top-K entries; round 3: the rank-only kernel's counter flush), and the checker flags the hand-written negative
+    fixture.  Needs hipcc only (cross-compiles without a GPU)."""
     import shutil
     import subprocess
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("hipcc not available")
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "deeprec_amd", "csrc"), "check"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", os.path.join(ROOT, "deeprec_amd", "csrc"), "check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert ", 0 violations" in r.stdout and "1 violations" in r.stdout
+    assert r.stdout.count(", 0 violations") >= 9 and "1 violations" in r.stdout
