@@ -27,21 +27,27 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ t
         int64_t id[U];
         int64_t row[U];
 #pragma unroll
+        // Loads are UNCONDITIONAL (a position past the end re-reads the last id, an id out of range reads row 0 and is
+        // zeroed by a select afterwards): written as `x = 0; if (ok) x = load(..)` every load was followed by its own
+        // s_waitcnt vmcnt(0) -- the U ids of a pass were U round trips in a row, not one.
         for (int p = 0; p < U; ++p) {
             row[p] = base + p * RPB + sub;
-            id[p] = (row[p] < n) ? (int64_t)ids[row[p]] : 0;
+            id[p] = (int64_t)ids[row[p] < n ? row[p] : n - 1];
         }
         for (int c = lane; c < cpr; c += LPR) {
             float v[U][V];
+            if (rows > 0) {
+#pragma unroll
+                for (int p = 0; p < U; ++p) {
+                    const bool ok = (id[p] >= 0) && (id[p] < rows);
+                    vload<V>(v[p], table + (ok ? id[p] : 0) * k + c * V);
+                }
+            }
 #pragma unroll
             for (int p = 0; p < U; ++p) {
                 const bool ok = (id[p] >= 0) && (id[p] < rows);
-                if (ok) {
-                    vload<V>(v[p], table + id[p] * k + c * V);
-                } else {
 #pragma unroll
-                    for (int x = 0; x < V; ++x) v[p][x] = 0.0f;
-                }
+                for (int x = 0; x < V; ++x) v[p][x] = ok ? v[p][x] : 0.0f;
             }
 #pragma unroll
             for (int p = 0; p < U; ++p) {

@@ -786,54 +786,58 @@ __global__ __launch_bounds__(256) void seg_update_kernel(SegArgs a) {
         int b, len;
         bool go;
     };
+    // Every load of the pipeline is UNCONDITIONAL (an index past the end re-reads a valid entry, the value is dropped
+    // by a select): written as `x = 0; if (ok) x = load(..)` each load was followed by its own s_waitcnt vmcnt(0), which
+    // also drained the row loads of the segment in flight -- the three stages ran one after the other.
+    if (s_hi <= s_lo) return;
     auto stage_a = [&](int s) {
         Seg g;
         g.go = s < s_hi;
-        g.r = 0;
-        g.b = 0;
-        g.len = 0;
-        if (g.go) {
-            g.r = (uint32_t)a.uniq[s] - a.id_lo;
-            g.b = a.seg_start[s];
-            g.len = a.seg_start[s + 1] - g.b;
-        }
+        const int sc = g.go ? s : s_hi - 1;
+        const uint32_t r = (uint32_t)a.uniq[sc] - a.id_lo;
+        const int b = a.seg_start[sc], e = a.seg_start[sc + 1];
+        g.r = g.go ? r : 0u;
+        g.b = g.go ? b : 0;
+        g.len = g.go ? e - b : 0;
         return g;
     };
     // sentinel segment of out-of-range ids / the other table's rows; long segments are seg_long_kernel's
     auto live = [&](const Seg& g) {
         return g.go && (int64_t)g.r < a.rows && g.len <= LONG_SEG && !(a.skip_single && g.len == 1);
     };
+    const int32_t* sposp = a.coef ? a.spos : a.msrc;   // without coefficients the positions are never used
+    auto load_idx = [&](const Seg& g, bool lv, int (&si)[4], int (&sp)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = g.b + ((lv && q < g.len) ? q : 0);   // g.b is a valid entry for every segment (and 0 for none)
+            si[q] = a.msrc[yy];
+            sp[q] = sposp[yy];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            si[q] = (lv && q < g.len) ? si[q] : -1;
+            sp[q] = (lv && q < g.len) ? sp[q] : 0;
+        }
+    };
     int s = s_lo + blockIdx.x * SPB + sub;
     Seg g0 = stage_a(s), g1 = stage_a(s + stride);
     int si0[4], sp0[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        si0[q] = -1;
-        sp0[q] = 0;
-        if (live(g0) && q < g0.len) {
-            si0[q] = a.msrc[g0.b + q];
-            if (a.coef) sp0[q] = a.spos[g0.b + q];
-        }
-    }
+    load_idx(g0, live(g0), si0, sp0);
     while (g0.go) {
         const Seg g2 = stage_a(s + 2 * stride);
         int si1[4], sp1[4];
-        const bool live1 = live(g1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            si1[q] = -1;
-            sp1[q] = 0;
-            if (live1 && q < g1.len) {
-                si1[q] = a.msrc[g1.b + q];
-                if (a.coef) sp1[q] = a.spos[g1.b + q];
-            }
-        }
+        load_idx(g1, live(g1), si1, sp1);
         if (live(g0)) {
             // the <= 4 contributions are resolved; every vector column issues its coefficient, source-row and
             // destination-row loads together (blocked order: a single block)
             float cf[4];
+            if (a.coef) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cf[q] = (a.coef && si0[q] >= 0) ? a.coef[sp0[q] - a.pos_lo] : 1.0f;
+                for (int q = 0; q < 4; ++q) cf[q] = a.coef[si0[q] >= 0 ? sp0[q] - a.pos_lo : 0];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cf[q] = 1.0f;
+            }
             for (int c = lane; c < cpr; c += LPR) {
                 float v[4][V], tot[V];
 #pragma unroll

@@ -19,7 +19,7 @@ loops = []
 for i, l in enumerate(body):
     t = l.split()
     if t and t[0].startswith(("s_cbranch", "s_branch")) and t[-1] in labels and labels[t[-1]] < i \
-            and "Loop Header" in raw[labels[t[-1]]]:
+            and i - labels[t[-1]] < 0.9 * len(body):      # (a branch back to an exit block at the top is no loop)
         loops.append((labels[t[-1]], i))
 best = max(loops, key=lambda ab: sum("v_mfma" in x for x in body[ab[0]:ab[1]]))
 
