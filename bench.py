@@ -377,12 +377,12 @@ def sharded_eval(args, K, sh, Pt, Qt, world, rank, device, barrier):
     Qf = sh.all_gather_table(Qt)
     barrier()
     t_rep = time.perf_counter() - t0
-    run = lambda: sh.sharded_eval_topk(K, Pt, Qt, users, 10, train=(tp, tr.reshape(-1).contiguous()), targets=(gp, tg), Q_full=Qf)
+    run = lambda: sh.sharded_eval_ranks(K, Pt, Qt, users, train=(tp, tr.reshape(-1).contiguous()), targets=(gp, tg), Q_full=Qf)
     run()
     barrier()
     t0 = time.perf_counter()
     for _ in range(iters):
-        idx, val, rk, _ = run()
+        rk, _ = run()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -395,6 +395,7 @@ def sharded_eval(args, K, sh, Pt, Qt, world, rank, device, barrier):
             "users_per_s": world * Nu * iters / dt, "TFLOPs": flops / dt / 1e12,
             "frac_mfma_f32_peak": flops / dt / 1e12 / (MFMA_F32_PEAK_TFLOPS * world),
             "item_table_all_gather_ms": t_rep * 1e3, "users_ranked": n, "hr@10": hr, "ndcg@10": ndcg, "mrr": mrr,
+            "path": "dr_score_rank_f32 (ranks of the held-out items; every @10 metric follows from them)",
             "parallelism": "users sharded x%d, item table replicated, user rows fetched from their owners" % world}
 
 

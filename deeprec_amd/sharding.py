@@ -524,6 +524,15 @@ def sharded_eval_topk(ops, P, Q, users, K, train=None, targets=None, Q_full=None
     return idx, val, rank, Q_full
 
 
+def sharded_eval_ranks(ops, P, Q, users, train=None, targets=None, Q_full=None, group=None):
+    """sharded_eval_topk without the top-K list: the ranks of the held-out items only (ops.score_rank: the streaming
+    kernel), which is all that reduce_rank_metrics and the reference's evaluators consume.  Returns (ranks, Q_full)."""
+    if Q_full is None:
+        Q_full = all_gather_table(Q, group)
+    U = fetch_rows(ops, P, users, group)
+    return ops.score_rank(U, Q_full, targets, train=train), Q_full
+
+
 def reduce_rank_metrics(ranks, K, group=None):
     """Leave-one-out metrics from this rank's target ranks (one held-out item per user; -1 = not a candidate),
     summed over all ranks: (users, hit-rate@K, NDCG@K, MRR).  One 4-float all-reduce."""

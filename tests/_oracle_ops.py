@@ -256,3 +256,8 @@ def score_topk(U, I, K, train=None, targets=None):
         idx[u, :len(top)], val[u, :len(top)] = top, tops
         ranks[gp[u]:gp[u + 1]] = rk
     return torch.from_numpy(idx), torch.from_numpy(val), (torch.from_numpy(ranks) if targets is not None else None)
+
+
+def score_rank(U, I, targets, train=None):
+    """Oracle-backed stand-in for kernels.score_rank (dot scores): the ranks score_topk reports."""
+    return score_topk(U, I, 1, train=train, targets=targets)[2]

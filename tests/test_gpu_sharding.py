@@ -371,6 +371,9 @@ def _eval_worker(rank, world, port, out):
         gp = np.arange(hi - lo + 1, dtype=np.int32)
         idx, val, rk, _ = sh.sharded_eval_topk(K, Pt, Qt, T(users[lo:hi], dev), 10, train=(T(tp, dev), T(ti, dev)),
                                                targets=(T(gp, dev), T(tgt[lo:hi], dev)))
+        rk2, _ = sh.sharded_eval_ranks(K, Pt, Qt, T(users[lo:hi], dev), train=(T(tp, dev), T(ti, dev)),
+                                       targets=(T(gp, dev), T(tgt[lo:hi], dev)))
+        assert torch.equal(rk2, rk)                 # the rank-only form (dr_score_rank_f32) returns the same ranks
         m = sh.reduce_rank_metrics(rk.cpu(), 10)
         parts = [None] * world
         dist.all_gather_object(parts, (N(idx), N(val), N(rk)))

@@ -152,6 +152,10 @@ def _eval_worker(rank, world, port, out):
         idx, val, rk, _ = sh.sharded_eval_topk(ops, Pt, Qt, torch.from_numpy(users[lo:hi]), K_,
                                                train=(torch.from_numpy(tp), torch.from_numpy(ti)),
                                                targets=(torch.from_numpy(gp), torch.from_numpy(tgt[lo:hi])))
+        rk2, _ = sh.sharded_eval_ranks(ops, Pt, Qt, torch.from_numpy(users[lo:hi]),
+                                       train=(torch.from_numpy(tp), torch.from_numpy(ti)),
+                                       targets=(torch.from_numpy(gp), torch.from_numpy(tgt[lo:hi])))
+        assert torch.equal(rk2, rk)                 # the rank-only form returns the same ranks
         m = sh.reduce_rank_metrics(rk, K_)
         parts = [None] * world
         dist.all_gather_object(parts, (idx.numpy(), rk.numpy()))
