@@ -336,6 +336,7 @@ class Shard:
 
     def __init__(self, world=1, rank=0, group=None, force=False):
         self.world, self.rank, self.group, self.force = int(world), int(rank), group, bool(force)
+        self._side, self._ids_group, self._pre = None, None, None
 
     @property
     def active(self):
@@ -348,10 +349,49 @@ class Shard:
         """This rank's rows of a replicated array / tensor."""
         return full[self.rank::self.world]
 
-    def step_route(self, lists):
-        """ONE route for all lookups of a training step (deeprec_amd/sharding.py:StepRoute): 3 collectives, 1 host sync."""
+    def step_route(self, lists, key=None):
+        """ONE route for all lookups of a training step (deeprec_amd/sharding.py:StepRoute): 3 collectives, 1 host sync.
+        lists: the id lists or a callable returning them; key: the step's input tensors -- a route that prefetch_route
+        built for the same tensors is taken over instead of built here."""
         from .. import sharding as sh
-        return sh.StepRoute(K, lists, self.world, self.rank, self.group)
+        pre, self._pre = self._pre, None
+        if pre is not None and key is not None and len(pre[0]) == len(key) and all(a is b for a, b in zip(pre[0], key)):
+            rt, ev = pre[1], pre[2]
+            if ev is not None:
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                rt.adopt(cur)
+            return rt
+        return sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group)
+
+    def prefetch_route(self, key, lists, ready=None):
+        """Build the route of a LATER step now: it depends on the step's ids only, so its id all-gather, bucketings and
+        host synchronisation run on a side stream / second communicator while the current step's kernels execute, and
+        the host blocks for the route alone instead of draining the step in flight.  key: the tensors the step will be
+        called with; ready: an event after which those tensors hold their values (default: everything enqueued on the
+        current stream so far).  Every rank calls it at the same point of its step sequence."""
+        from .. import sharding as sh
+        import torch.distributed as dist
+        first = key[0]
+        if not first.is_cuda:                               # CPU (gloo) runs: no streams, the route is simply built early
+            self._pre = (tuple(key), sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group), None)
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=first.device)
+            if dist.is_available() and dist.is_initialized():
+                ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+                self._ids_group = dist.new_group(ranks=ranks)
+        side = self._side
+        if ready is not None:
+            side.wait_event(ready)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            rt = sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group,
+                              ids_group=self._ids_group)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._pre = (tuple(key), rt, ev)
 
     def all_reduce_grads(self, params):
         """Data-parallel dense weights: the per-rank gradients summed in ONE all-reduce of their concatenation."""

@@ -127,7 +127,8 @@ class AttRec(SeqBase):
         P, X, Q, Qs, items, rt = self.P, self.X, self.Q, self.Q, None, None
         if self.shard:
             T_ = item_id.shape[1]
-            rt = self.shard.step_route([item_seq, user_id, torch.cat((item_id, neg_item_id), 1)])
+            rt = self.shard.step_route(lambda: [item_seq, user_id, torch.cat((item_id, neg_item_id), 1)],
+                                       key=(user_id, item_seq, item_id, neg_item_id))
             Qs, P, X, Q = rt.fetch([(self.Q, 0), (self.P, 1), (self.X, 2), (self.Q, 2)])
             item_seq, user_id, items = rt.pos(0), rt.pos(1), rt.pos(2)      # positions in the fetched rows
             item_id, neg_item_id = items[:, :T_].contiguous(), items[:, T_:].contiguous()
@@ -145,6 +146,13 @@ class AttRec(SeqBase):
             rt.push()
             self.shard.all_reduce_grads([self.linear_project])
         return loss.detach()
+
+    def prefetch(self, user_id, item_seq, item_id, neg_item_id, ready=None):
+        """Data-parallel only: build the route of a later train_op(user_id, item_seq, item_id, neg_item_id) call now, beside
+        the step in flight (_common.Shard.prefetch_route).  The step must be called with these very tensors."""
+        if self.shard:
+            self.shard.prefetch_route((user_id, item_seq, item_id, neg_item_id),
+                                      lambda: [item_seq, user_id, torch.cat((item_id, neg_item_id), 1)], ready=ready)
 
     def _apply_step(self):
         o = self.optimizer

@@ -197,7 +197,8 @@ class Caser(SeqBase):
         scale = self.loss_scale
         if self.shard:
             T_ = item_id.shape[1]
-            rt = self.shard.step_route([item_seq, user_id, torch.cat((item_id, neg_item_id), 1)])
+            rt = self.shard.step_route(lambda: [item_seq, user_id, torch.cat((item_id, neg_item_id), 1)],
+                                       key=(user_id, item_seq, item_id, neg_item_id))
             Qs, P, W, b = rt.fetch([(self.Q, 0), (self.P, 1), (self.W, 2), (self.b, 2)])
             item_seq, user_id, items = rt.pos(0), rt.pos(1), rt.pos(2)      # positions in the fetched rows
             item_id, neg_item_id = items[:, :T_].contiguous(), items[:, T_:].contiguous()
@@ -216,6 +217,13 @@ class Caser(SeqBase):
             rt.push()
             self.shard.all_reduce_grads(self._dense_params())
         return loss.detach()
+
+    def prefetch(self, user_id, item_seq, item_id, neg_item_id, ready=None):
+        """Data-parallel only: build the route of a later train_op(user_id, item_seq, item_id, neg_item_id) call now, beside
+        the step in flight (_common.Shard.prefetch_route).  The step must be called with these very tensors."""
+        if self.shard:
+            self.shard.prefetch_route((user_id, item_seq, item_id, neg_item_id),
+                                      lambda: [item_seq, user_id, torch.cat((item_id, neg_item_id), 1)], ready=ready)
 
     def _apply_step(self):
         o = self.optimizer

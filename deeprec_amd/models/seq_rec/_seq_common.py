@@ -80,14 +80,26 @@ class SeqBase:
         else:
             n_d = to_dev(self._epoch_negatives(usr_r, tar_r, n_neg), torch.int32, dev)
         step = getattr(self, "_step", None) or self.train_op
-        for i in range(self.total_batch):
-            start_time = time.time()
+        sh = getattr(self, "shard", None)
+
+        def batch(i):
             sl = slice(i * self.batch_size, (i + 1) * self.batch_size)
-            sh = getattr(self, "shard", None)
             if sh:          # data-parallel: this rank's contiguous part of the batch (same permutation on every rank)
                 per = self.batch_size // sh.world
                 sl = slice(i * self.batch_size + sh.rank * per, i * self.batch_size + (sh.rank + 1) * per)
-            loss = step(u_d[sl].contiguous(), s_d[sl].contiguous(), t_d[sl].contiguous(), n_d[sl].contiguous())
+            return u_d[sl].contiguous(), s_d[sl].contiguous(), t_d[sl].contiguous(), n_d[sl].contiguous()   # views
+        ahead = sh and hasattr(self, "prefetch")
+        ready = None
+        if ahead and u_d.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record()                                   # the epoch's ids are resident from here on
+        nxt = batch(0) if self.total_batch > 0 else None
+        for i in range(self.total_batch):
+            start_time = time.time()
+            cur, nxt = nxt, (batch(i + 1) if i + 1 < self.total_batch else None)
+            loss = step(*cur)
+            if ahead and nxt is not None:                    # the next step's route beside this step's kernels
+                self.prefetch(*nxt, ready=ready)
             if i % self.display_step == 0:
                 if self.verbose:
                     print("Index: %04d; cost= %.9f" % (i + 1, float(loss.item())))

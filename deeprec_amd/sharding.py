@@ -354,7 +354,9 @@ class StepRoute:
     below: a count exchange, a host synchronisation and three all-to-alls per lookup).  Rows of different widths share
     the wire: a peer's block holds one 16-byte-aligned segment per (table, list) pair (csrc/wire.hip)."""
 
-    def __init__(self, ops, lists, world, rank, group=None):
+    def __init__(self, ops, lists, world, rank, group=None, ids_group=None):
+        """ids_group: the communicator of the id all-gather when the route is built ahead of its step on another stream
+        (models/_common.py: Shard.prefetch_route); fetch / push always use `group`."""
         self.ops, self.world, self.rank, self.group = ops, int(world), int(rank), group
         W, nl = self.world, len(lists)
         flat = [t.reshape(-1) if t.dtype == torch.int32 else t.reshape(-1).to(torch.int32) for t in lists]
@@ -367,7 +369,7 @@ class StepRoute:
         mine = (torch.cat(flat) if nl > 1 else flat[0]).contiguous()
         dev = mine.device
         ids_all = torch.empty((W, n_tot), dtype=torch.int32, device=dev)
-        _gather_ids(ids_all, mine, group)                                   # collective 1 of 3
+        _gather_ids(ids_all, mine, ids_group if ids_group is not None else group)   # collective 1 of 3
         km, ko, loc = ops.step_route_keys(ids_all, self.rank, self.start)
         order_m, cnt_m = ops.bucket_order(km, nl * W)                       # my entries by (list, owner)
         order_o, cnt_o = ops.bucket_order(ko, nl * W)                       # entries I own by (list, source rank)
@@ -384,6 +386,13 @@ class StepRoute:
             off += self.n_own[l]
         self._pos = [None] * nl
         self._specs, self._fetched, self._order = None, [], []
+        self._made = [order_m, loc] + list(self.want)       # device tensors a later stream will read (adopt())
+
+    def adopt(self, stream):
+        """The route was built on another stream: its tensors are read on `stream` from now on (caching allocator)."""
+        for t in self._made:
+            if t.is_cuda:
+                t.record_stream(stream)
 
     def pos(self, l):
         """Positions 0 .. n_l - 1 in the shape of list l: what a lookup in the fetched rows is addressed with."""

@@ -481,14 +481,20 @@ def _seq_worker(rank, world, port, cls_name, out):
         m, steps = _seq_model(cls_name, dev, Shard(world, rank))
         per = len(steps[0][0]) // world
         losses = []
-        for b in steps:
-            mine = tuple(T(x[rank * per:(rank + 1) * per], dev) for x in b)
+        mines = [tuple(T(x[rank * per:(rank + 1) * per], dev) for x in b) for b in steps]
+        total = 0
+        for i, mine in enumerate(mines):
             calls["collectives"] = 0
             l = m.train_op(*mine).cpu()
-            # id all-gather + rows in + gradient rows out + ONE all-reduce of the dense gradients, for 4 lookups in 4 tables
-            assert calls["collectives"] == 4, calls
+            # id all-gather + rows in + gradient rows out + ONE all-reduce of the dense gradients, for 4 lookups in 4 tables;
+            # from the second step on the id all-gather has happened in the previous step's prefetch
+            assert calls["collectives"] == (4 if i == 0 else 3), calls
+            if i + 1 < len(mines):
+                m.prefetch(*mines[i + 1])         # the next step's route, built beside this step (side stream, 2nd group)
+            total += calls["collectives"]
             dist.all_reduce(l)
             losses.append(float(l))
+        assert total == 4 * len(mines)
         res = {}
         names = [n for n in ("P", "V", "Q", "X", "W", "b") if hasattr(m, n)]
         for n in names:
@@ -585,14 +591,93 @@ def test_seq_models_world1_through_rccl_equal_unsharded(dev, cls_name):
         m1, _ = _seq_model(cls_name, dev, Shard(1, 0, force=True))
         assert m1.shard is not None and m1.Q.shard is not None
         got = [float(m1.train_op(*(T(x, dev) for x in b))) for b in steps]
+        # the same with every route after the first built ahead of its step (Shard.prefetch_route: side stream, second
+        # communicator): the route depends on the ids only, so nothing may change
+        m2, _ = _seq_model(cls_name, dev, Shard(1, 0, force=True))
+        bs = [tuple(T(x, dev) for x in b) for b in steps]
+        got2 = []
+        for i, b in enumerate(bs):
+            got2.append(float(m2.train_op(*b)))
+            if i + 1 < len(bs):
+                m2.prefetch(*bs[i + 1])
+                assert m2.shard._pre is not None
+        assert m2.shard._pre is None            # every prefetched route was taken over by its step
     finally:
         dist.destroy_process_group()
-    assert got == want
+    assert got == want and got2 == want
+    for n in ("P", "V", "Q", "X", "W", "b"):
+        if hasattr(m0, n):
+            _same(N(getattr(m2, n).w), N(getattr(m0, n).w), cls_name + ".prefetch." + n)
     for n in ("P", "V", "Q", "X", "W", "b"):
         if hasattr(m0, n):
             _same(N(getattr(m1, n).w), N(getattr(m0, n).w), cls_name + "." + n)
     for (n, a), b in zip(_seq_dense(cls_name, m1).items(), _seq_dense(cls_name, m0).values()):
         _same(N(a), N(b), cls_name + "." + n)
+
+
+@pytest.mark.parametrize("cls_name", ["AttRec", "Caser"])
+def test_seq_epoch_world1_through_rccl_prefetches_routes_and_equals_unsharded(dev, tmp_path, cls_name):
+    """model.train() (one epoch of _seq_common._train_epoch) with Shard(1, 0, force=True): every route after the first is
+    built ahead of its step (side stream, second communicator) and taken over by it; tables after the epoch are
+    bit-identical to the unsharded model's."""
+    import contextlib
+    import io
+    import torch.distributed as dist
+    from deeprec_amd import sharding as sh
+    from deeprec_amd.models._common import Shard
+    from deeprec_amd.models.seq_rec.AttRec import AttRec
+    from deeprec_amd.models.seq_rec.Caser import Caser
+    from deeprec_amd.utils.load_data.load_data_seq import DataSet
+    rng = np.random.default_rng(9)
+    nu, ni, L, T_ = 60, 50, 3, 2
+    lines = []
+    for u in range(nu):
+        for it in rng.permutation(ni)[:int(rng.integers(L + T_ + 2, L + T_ + 8))]:
+            lines.append("%d %d 1\n" % (u + 1, it + 1))
+    ptr = tmp_path / "train.txt"
+    ptr.write_text("".join(lines))
+    pte = tmp_path / "test.txt"
+    pte.write_text("".join("%d %d 1\n" % (u + 1, int(rng.integers(1, ni + 1))) for u in range(nu)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        train = DataSet(str(ptr), ['user', 'item', 'rating'], " ", L, T_, True)
+        test = DataSet(str(pte), ['user', 'item', 'rating'], " ", 1, 1, False, train.user_map, train.item_map,
+                       train.num_user, train.num_item)
+    cls = AttRec if cls_name == "AttRec" else Caser
+    kw = dict(num_factor=16) if cls is AttRec else dict(num_factor=16, n_h=4, n_v=2)
+
+    def epoch(shard):
+        with contextlib.redirect_stdout(io.StringIO()):
+            torch.manual_seed(1)
+            np.random.seed(1)
+            m = cls(None, train.num_user, train.num_item, 0.05 if cls is AttRec else 0.001, 0.01, 1, 16, shard=shard)
+            m.build_network(L, T_, **kw)
+            m.prepare_data(train, test)
+            np.random.seed(2)
+            m.train(train)
+        return m
+    m0 = epoch(None)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        built = {"ahead": 0, "all": 0}
+        init = sh.StepRoute.__init__
+
+        def counting(self, *a, ids_group=None, **k):
+            built["all"] += 1
+            built["ahead"] += ids_group is not None
+            return init(self, *a, ids_group=ids_group, **k)
+        sh.StepRoute.__init__ = counting
+        try:
+            m1 = epoch(Shard(1, 0, force=True))
+        finally:
+            sh.StepRoute.__init__ = init
+        assert m1.total_batch >= 3 and built["all"] == m1.total_batch and built["ahead"] == m1.total_batch - 1, built
+        assert m1.shard._pre is None
+    finally:
+        dist.destroy_process_group()
+    for n in ("P", "V", "Q", "X", "W", "b"):
+        if hasattr(m0, n):
+            _same(N(getattr(m1, n).w), N(getattr(m0, n).w), cls_name + ".epoch." + n)
 
 
 # ------------------------------------------------------------------ the route's kernels vs their numpy restatement
