@@ -6,6 +6,8 @@ PyTorch is used for device memory, autograd bookkeeping and the small dense laye
 GEMMs and convolutions); every embedding lookup, duplicate-summing backward, optimizer application, fused
 step and full-catalog evaluation goes through the C ABI (deeprec_amd.kernels).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -377,7 +379,7 @@ class Shard:
             self._pre = (tuple(key), sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group), None)
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=first.device)
+            self._side = torch.cuda.Stream(device=first.device, priority=int(os.environ.get("DR_ROUTE_PRIO", "-1")))
             if dist.is_available() and dist.is_initialized():
                 ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
                 self._ids_group = dist.new_group(ranks=ranks)
