@@ -338,7 +338,8 @@ class Shard:
 
     def __init__(self, world=1, rank=0, group=None, force=False):
         self.world, self.rank, self.group, self.force = int(world), int(rank), group, bool(force)
-        self._side, self._ids_group, self._pre = None, None, None
+        self._pre = []                                      # routes enqueued ahead of their steps: [(key tensors, StepRoute)]
+        self._side, self._ids_group = None, None
 
     @property
     def active(self):
@@ -354,46 +355,41 @@ class Shard:
     def step_route(self, lists, key=None):
         """ONE route for all lookups of a training step (deeprec_amd/sharding.py:StepRoute): 3 collectives, 1 host sync.
         lists: the id lists or a callable returning them; key: the step's input tensors -- a route that prefetch_route
-        built for the same tensors is taken over instead of built here."""
+        enqueued for the same tensors is finished here instead of built."""
         from .. import sharding as sh
-        pre, self._pre = self._pre, None
-        if pre is not None and key is not None and len(pre[0]) == len(key) and all(a is b for a, b in zip(pre[0], key)):
-            rt, ev = pre[1], pre[2]
-            if ev is not None:
-                cur = torch.cuda.current_stream()
-                cur.wait_event(ev)
-                rt.adopt(cur)
-            return rt
+        if key is not None:
+            for n, (k2, rt) in enumerate(self._pre):
+                if len(k2) == len(key) and all(a is b for a, b in zip(k2, key)):
+                    del self._pre[n]
+                    rt.finish()
+                    return rt
         return sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group)
 
-    def prefetch_route(self, key, lists, ready=None):
-        """Build the route of a LATER step now: it depends on the step's ids only, so its id all-gather, bucketings and
-        host synchronisation run on a side stream / second communicator while the current step's kernels execute, and
-        the host blocks for the route alone instead of draining the step in flight.  key: the tensors the step will be
-        called with; ready: an event after which those tensors hold their values (default: everything enqueued on the
-        current stream so far).  Every rank calls it at the same point of its step sequence."""
+    def prefetch_route(self, key, lists):
+        """Enqueue the id-only part of a LATER step's route now (its id all-gather, bucketings and the copy of the counts to
+        pinned host memory).  Called BEFORE the current step is
+        enqueued, the route's kernels run ahead of that step's, so when the later step asks for the route its event
+        has long been reached and the step's one host synchronisation does not drain the work in flight.  key: the
+        tensors the later step will be called with.  Every rank calls it at the same point of its step sequence."""
         from .. import sharding as sh
         import torch.distributed as dist
-        first = key[0]
-        if not first.is_cuda:                               # CPU (gloo) runs: no streams, the route is simply built early
-            self._pre = (tuple(key), sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group), None)
-            return
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=first.device, priority=int(os.environ.get("DR_ROUTE_PRIO", "-1")))
-            if dist.is_available() and dist.is_initialized():
-                ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
-                self._ids_group = dist.new_group(ranks=ranks)
-        side = self._side
-        if ready is not None:
-            side.wait_event(ready)
+        if not key[0].is_cuda or os.environ.get("DR_ROUTE_STREAM", "1") == "0":
+            rt = sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group, defer=True)
         else:
-            side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            rt = sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group,
-                              ids_group=self._ids_group)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self._pre = (tuple(key), rt, ev)
+            # on a stream (and communicator) of its own: where the hardware queues allow it the route's short kernels run
+            # BESIDE the step enqueued next; where the two streams share a queue they run ahead of it, as in-stream
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=key[0].device, priority=-1)
+                if dist.is_available() and dist.is_initialized():
+                    ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+                    self._ids_group = dist.new_group(ranks=ranks)
+            self._side.wait_stream(torch.cuda.current_stream())     # the ids are ready; earlier steps are not overtaken
+            with torch.cuda.stream(self._side):
+                rt = sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group, defer=True,
+                                  ids_group=self._ids_group)
+        self._pre.append((tuple(key), rt))
+        if len(self._pre) > 2:                              # routes nobody came for
+            del self._pre[0]
 
     def all_reduce_grads(self, params):
         """Data-parallel dense weights: the per-rank gradients summed in ONE all-reduce of their concatenation."""

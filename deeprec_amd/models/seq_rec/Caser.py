@@ -218,12 +218,13 @@ class Caser(SeqBase):
             self.shard.all_reduce_grads(self._dense_params())
         return loss.detach()
 
-    def prefetch(self, user_id, item_seq, item_id, neg_item_id, ready=None):
-        """Data-parallel only: build the route of a later train_op(user_id, item_seq, item_id, neg_item_id) call now, beside
-        the step in flight (_common.Shard.prefetch_route).  The step must be called with these very tensors."""
+    def prefetch(self, user_id, item_seq, item_id, neg_item_id):
+        """Data-parallel only: enqueue the route of a LATER train_op(user_id, item_seq, item_id, neg_item_id) call now
+        (_common.Shard.prefetch_route) -- call it before the train_op of the step in between; the later step must be
+        called with these very tensors."""
         if self.shard:
             self.shard.prefetch_route((user_id, item_seq, item_id, neg_item_id),
-                                      lambda: [item_seq, user_id, torch.cat((item_id, neg_item_id), 1)], ready=ready)
+                                      lambda: [item_seq, user_id, torch.cat((item_id, neg_item_id), 1)])
 
     def _apply_step(self):
         o = self.optimizer

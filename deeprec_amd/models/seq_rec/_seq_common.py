@@ -89,17 +89,13 @@ class SeqBase:
                 sl = slice(i * self.batch_size + sh.rank * per, i * self.batch_size + (sh.rank + 1) * per)
             return u_d[sl].contiguous(), s_d[sl].contiguous(), t_d[sl].contiguous(), n_d[sl].contiguous()   # views
         ahead = sh and hasattr(self, "prefetch")
-        ready = None
-        if ahead and u_d.is_cuda:
-            ready = torch.cuda.Event()
-            ready.record()                                   # the epoch's ids are resident from here on
         nxt = batch(0) if self.total_batch > 0 else None
         for i in range(self.total_batch):
             start_time = time.time()
             cur, nxt = nxt, (batch(i + 1) if i + 1 < self.total_batch else None)
+            if ahead and nxt is not None:                    # the next step's route is enqueued ahead of this step
+                self.prefetch(*nxt)
             loss = step(*cur)
-            if ahead and nxt is not None:                    # the next step's route beside this step's kernels
-                self.prefetch(*nxt, ready=ready)
             if i % self.display_step == 0:
                 if self.verbose:
                     print("Index: %04d; cost= %.9f" % (i + 1, float(loss.item())))

@@ -354,9 +354,12 @@ class StepRoute:
     below: a count exchange, a host synchronisation and three all-to-alls per lookup).  Rows of different widths share
     the wire: a peer's block holds one 16-byte-aligned segment per (table, list) pair (csrc/wire.hip)."""
 
-    def __init__(self, ops, lists, world, rank, group=None, ids_group=None):
-        """ids_group: the communicator of the id all-gather when the route is built ahead of its step on another stream
-        (models/_common.py: Shard.prefetch_route); fetch / push always use `group`."""
+    def __init__(self, ops, lists, world, rank, group=None, defer=False, ids_group=None):
+        """defer: enqueue the id-only part (all-gather, keys, bucketings, counts -> pinned host memory) and return; finish()
+        -- called by the step that uses the route -- waits for an event recorded behind those kernels.  A route built
+        one step AHEAD (models/_common.py: Shard.prefetch_route, enqueued before the previous step's kernels) is complete
+        by then, so the step's one host synchronisation no longer drains the work in flight.  ids_group: the
+        communicator of the id all-gather when that part is enqueued on another stream than the step's."""
         self.ops, self.world, self.rank, self.group = ops, int(world), int(rank), group
         W, nl = self.world, len(lists)
         flat = [t.reshape(-1) if t.dtype == torch.int32 else t.reshape(-1).to(torch.int32) for t in lists]
@@ -370,29 +373,47 @@ class StepRoute:
         dev = mine.device
         ids_all = torch.empty((W, n_tot), dtype=torch.int32, device=dev)
         _gather_ids(ids_all, mine, ids_group if ids_group is not None else group)   # collective 1 of 3
-        km, ko, loc = ops.step_route_keys(ids_all, self.rank, self.start)
-        order_m, cnt_m = ops.bucket_order(km, nl * W)                       # my entries by (list, owner)
-        order_o, cnt_o = ops.bucket_order(ko, nl * W)                       # entries I own by (list, source rank)
-        c = torch.cat((cnt_m[:nl * W], cnt_o[:nl * W])).tolist()            # the ONE host synchronisation of a step
+        km, ko, self._loc = ops.step_route_keys(ids_all, self.rank, self.start)
+        self._order_m, cnt_m = ops.bucket_order(km, nl * W)                 # my entries by (list, owner)
+        self._order_o, cnt_o = ops.bucket_order(ko, nl * W)                 # entries I own by (list, source rank)
+        cnt = torch.cat((cnt_m[:nl * W], cnt_o[:nl * W]))
+        self._ev = None
+        if cnt.is_cuda:
+            self._cnt_host = torch.empty(cnt.numel(), dtype=cnt.dtype, pin_memory=True)
+            self._cnt_host.copy_(cnt, non_blocking=True)
+            self._ev = torch.cuda.Event()
+            self._ev.record()
+        else:
+            self._cnt_host = cnt
+        self._pos = [None] * nl
+        self._specs, self._fetched, self._order = None, [], []
+        self._done = False
+        if not defer:
+            self.finish()
+
+    def finish(self):
+        """The ONE host synchronisation of a step: the per-(list, peer) counts, then the host-side slicing that needs them."""
+        if self._done:
+            return
+        self._done = True
+        W, nl = self.world, len(self.n)
+        if self._ev is not None:
+            self._ev.synchronize()
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._ev)                  # no-ops when the id-only part ran on this stream
+            for t in (self._order_m, self._order_o, self._loc):
+                t.record_stream(cur)
+        c = self._cnt_host.tolist()
         self.send_cnt = [c[l * W:(l + 1) * W] for l in range(nl)]           # [list][owner]: rows I ask of each owner
         self.recv_cnt = [c[(nl + l) * W:(nl + l + 1) * W] for l in range(nl)]   # [list][source]: rows each peer asks of me
         self.n_own = [sum(r) for r in self.recv_cnt]
         # my entries of list l in wire order (by owner, then list position): positions in `mine`, bias start[l]
-        self.send_idx = [order_m[self.start[l]:self.start[l + 1]] for l in range(nl)]
+        self.send_idx = [self._order_m[self.start[l]:self.start[l + 1]] for l in range(nl)]
         # local rows the peers ask of me, by source rank, each source's in its list order
         self.want, off = [], 0
         for l in range(nl):
-            self.want.append(torch.index_select(loc, 0, order_o[off:off + self.n_own[l]]))
+            self.want.append(torch.index_select(self._loc, 0, self._order_o[off:off + self.n_own[l]]))
             off += self.n_own[l]
-        self._pos = [None] * nl
-        self._specs, self._fetched, self._order = None, [], []
-        self._made = [order_m, loc] + list(self.want)       # device tensors a later stream will read (adopt())
-
-    def adopt(self, stream):
-        """The route was built on another stream: its tensors are read on `stream` from now on (caching allocator)."""
-        for t in self._made:
-            if t.is_cuda:
-                t.record_stream(stream)
 
     def pos(self, l):
         """Positions 0 .. n_l - 1 in the shape of list l: what a lookup in the fetched rows is addressed with."""

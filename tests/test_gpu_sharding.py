@@ -485,13 +485,15 @@ def _seq_worker(rank, world, port, cls_name, out):
         total = 0
         for i, mine in enumerate(mines):
             calls["collectives"] = 0
+            if i + 1 < len(mines):
+                m.prefetch(*mines[i + 1])         # the next step's route (ids only) is enqueued ahead of this step
+                assert calls["collectives"] == 1
+            calls["collectives"] = 0
             l = m.train_op(*mine).cpu()
             # id all-gather + rows in + gradient rows out + ONE all-reduce of the dense gradients, for 4 lookups in 4 tables;
             # from the second step on the id all-gather has happened in the previous step's prefetch
             assert calls["collectives"] == (4 if i == 0 else 3), calls
-            if i + 1 < len(mines):
-                m.prefetch(*mines[i + 1])         # the next step's route, built beside this step (side stream, 2nd group)
-            total += calls["collectives"]
+            total += calls["collectives"] + (1 if i + 1 < len(mines) else 0)
             dist.all_reduce(l)
             losses.append(float(l))
         assert total == 4 * len(mines)
@@ -591,17 +593,17 @@ def test_seq_models_world1_through_rccl_equal_unsharded(dev, cls_name):
         m1, _ = _seq_model(cls_name, dev, Shard(1, 0, force=True))
         assert m1.shard is not None and m1.Q.shard is not None
         got = [float(m1.train_op(*(T(x, dev) for x in b))) for b in steps]
-        # the same with every route after the first built ahead of its step (Shard.prefetch_route: side stream, second
-        # communicator): the route depends on the ids only, so nothing may change
+        # the same with every route after the first enqueued one step ahead (Shard.prefetch_route): the route depends on
+        # the ids only, so nothing may change
         m2, _ = _seq_model(cls_name, dev, Shard(1, 0, force=True))
         bs = [tuple(T(x, dev) for x in b) for b in steps]
         got2 = []
         for i, b in enumerate(bs):
-            got2.append(float(m2.train_op(*b)))
             if i + 1 < len(bs):
                 m2.prefetch(*bs[i + 1])
-                assert m2.shard._pre is not None
-        assert m2.shard._pre is None            # every prefetched route was taken over by its step
+                assert len(m2.shard._pre) == 1 + (i > 0)
+            got2.append(float(m2.train_op(*b)))
+        assert m2.shard._pre == []              # every prefetched route was taken over by its step
     finally:
         dist.destroy_process_group()
     assert got == want and got2 == want
@@ -618,7 +620,7 @@ def test_seq_models_world1_through_rccl_equal_unsharded(dev, cls_name):
 @pytest.mark.parametrize("cls_name", ["AttRec", "Caser"])
 def test_seq_epoch_world1_through_rccl_prefetches_routes_and_equals_unsharded(dev, tmp_path, cls_name):
     """model.train() (one epoch of _seq_common._train_epoch) with Shard(1, 0, force=True): every route after the first is
-    built ahead of its step (side stream, second communicator) and taken over by it; tables after the epoch are
+    enqueued one step ahead of its step and finished by it; tables after the epoch are
     bit-identical to the unsharded model's."""
     import contextlib
     import io
@@ -662,17 +664,17 @@ def test_seq_epoch_world1_through_rccl_prefetches_routes_and_equals_unsharded(de
         built = {"ahead": 0, "all": 0}
         init = sh.StepRoute.__init__
 
-        def counting(self, *a, ids_group=None, **k):
+        def counting(self, *a, defer=False, **k):
             built["all"] += 1
-            built["ahead"] += ids_group is not None
-            return init(self, *a, ids_group=ids_group, **k)
+            built["ahead"] += bool(defer)
+            return init(self, *a, defer=defer, **k)
         sh.StepRoute.__init__ = counting
         try:
             m1 = epoch(Shard(1, 0, force=True))
         finally:
             sh.StepRoute.__init__ = init
         assert m1.total_batch >= 3 and built["all"] == m1.total_batch and built["ahead"] == m1.total_batch - 1, built
-        assert m1.shard._pre is None
+        assert m1.shard._pre == []
     finally:
         dist.destroy_process_group()
     for n in ("P", "V", "Q", "X", "W", "b"):

@@ -162,22 +162,19 @@ def main():
         m = quiet(cls, None, nu, ni, 0.05 if cls is AttRec else 0.001, 0.01, 1, B, shard=Shard(1, 0, force=True))
         quiet(m.build_network, L, T_, **kw)
         ms_np = timed(lambda: m.train_op(*bs[next(it) % 4]), 20, 3)
-        ready = torch.cuda.Event()
-        ready.record()
         state = {"i": 0}
 
-        def ahead():                # as _train_epoch runs it: the next step's route is built beside this step's kernels
+        def ahead():                # as _train_epoch runs it: the next step's route is enqueued ahead of this step
             i = state["i"]
             state["i"] = i + 1
+            m.prefetch(*bs[(i + 1) % 4])
             m.train_op(*bs[i % 4])
-            m.prefetch(*bs[(i + 1) % 4], ready=ready)
         ms_sh = timed(ahead, 20, 3)
-        m.shard._pre = None
+        m.shard._pre = []
         out["C5_%s" % name]["ms_per_step_sharded_world1_rccl"] = ms_sh
         out["C5_%s" % name]["ms_per_step_sharded_world1_rccl_route_not_prefetched"] = ms_np
         out["C5_%s" % name]["sharded_step"] = ("3 collectives (ids, rows in, gradient rows out) + 1 all-reduce, 1 host sync; the "
-                                               "route of step t + 1 (ids only) is built on a side stream / second communicator "
-                                               "while step t runs")
+                                               "route of step t + 1 (ids only) is enqueued ahead of step t, so the sync finds it done")
         del m
         torch.cuda.empty_cache()
     say("   C5 eval")

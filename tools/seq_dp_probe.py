@@ -47,18 +47,17 @@ def main():
             return r
         setattr(obj, attr, g)
     wrap(sh.StepRoute, "__init__", "route")
+    wrap(sh.StepRoute, "finish", "route_finish")
     wrap(sh.StepRoute, "fetch", "fetch")
     wrap(sh.StepRoute, "push", "push")
     wrap(m, "_apply_step", "apply")
 
-    ready = torch.cuda.Event()
-    ready.record()
-
     def run(n):
         for i in range(n):
-            m.train_op(*bs[i % 4])
             if prefetch:
-                m.prefetch(*bs[(i + 1) % 4], ready=ready)
+                m.prefetch(*bs[(i + 1) % 4])
+            m.train_op(*bs[i % 4])
+        m.shard._pre = []
     run(5)
     torch.cuda.synchronize()
     acc.clear()
