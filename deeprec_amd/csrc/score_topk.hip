@@ -769,6 +769,12 @@ __device__ long long dbg_trace[4096 * DBG_STRIDE];
 #else
 #define DR_TRACE(slot)
 #endif
+// (Round 3, measured and removed: the rank-only kernel's pipelined epilogue -- tile t - 1's compares and candidate stores
+// behind tile t's MFMA chain on a second accumulator, thresholds re-read from LDS, candidates folded one barrier later,
+// row words double-buffered -- is bit-identical here too (69 scoring tests) but SLOWER at C4 shape: 43.4 ms against
+// 42.2; as two renamed copies of the loop body 44.2 ms, and that structure without the pipelining 48.6 ms.  The two
+// co-resident workgroups of this kernel already run in anti-phase, so the drain it hides is covered by the other
+// workgroup's chain, and the loop is sensitive to code size.)
 template <int KS, bool VEC, bool AFFINE>
 __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
     using G = Geo<KS, VEC>;
