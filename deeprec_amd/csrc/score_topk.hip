@@ -1126,6 +1126,9 @@ __global__ __launch_bounds__(256, 2) void score_kernel_t1(ScoreArgs a) {
 #define DR_RK_PIPE 1   // the epilogue of tile t runs behind the MFMA chain of tile t + 1 (second accumulator)
 #endif
 // (requesting a stage's first B operands right behind the barrier, ahead of the stage's stores and loads: no change, 38.0 ms)
+// (stages of TWO item tiles -- one barrier per 128 MFMAs of a wave, four 33 KB tile buffers, both epilogues behind the second
+// chain: bit-identical, 36.1 ms against 34.8 at C4 shape; one loop body with a 16-register accumulator copy instead of two
+// renamed copies: 34.8 against 34.9 -- neither kept)
 #ifndef DR_RK_PIN
 #define DR_RK_PIN 1
 #endif
