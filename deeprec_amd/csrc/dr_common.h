@@ -158,6 +158,36 @@ __device__ __forceinline__ void vstore(float* p, const float (&r)[V]) {
     }
 }
 
+// the same with the non-temporal hint (rows that are touched once per step: no reuse to keep in L2 / Infinity Cache)
+template <int V>
+__device__ __forceinline__ void vload_nt(float (&r)[V], const float* p) {
+    if constexpr (V == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+    } else if constexpr (V == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 t = __builtin_nontemporal_load(reinterpret_cast<const f2*>(p));
+        r[0] = t.x; r[1] = t.y;
+    } else {
+        r[0] = __builtin_nontemporal_load(p);
+    }
+}
+template <int V>
+__device__ __forceinline__ void vstore_nt(float* p, const float (&r)[V]) {
+    if constexpr (V == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 t = {r[0], r[1], r[2], r[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
+    } else if constexpr (V == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 t = {r[0], r[1]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f2*>(p));
+    } else {
+        __builtin_nontemporal_store(r[0], p);
+    }
+}
+
 // sum over the LPR lanes that share a row (xor butterfly; every lane gets the result)
 template <int LPR>
 __device__ __forceinline__ float subwave_sum(float x) {

@@ -121,7 +121,7 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, uint32_t r, int c, f
 __device__ __forceinline__ int kind_slots(int kind) {
     return kind == DR_OPT_SGD ? 0 : ((kind == DR_OPT_ADAM || kind == DR_OPT_RMSPROP) ? 2 : 1);
 }
-template <int V, int KIND = KIND_ANY>
+template <int V, int KIND = KIND_ANY, bool NT = false>
 __device__ __forceinline__ void apply_row_loaded(const SegArgs& a, uint32_t r, int c, float (&tot)[V], float (&w)[V],
                                                  float (&s0)[V], float (&s1)[V]) {
     const int64_t off = (int64_t)r * a.k + c * V;
@@ -132,9 +132,15 @@ __device__ __forceinline__ void apply_row_loaded(const SegArgs& a, uint32_t r, i
     if (KIND == DR_OPT_ADAM) {  // the hot instantiation: no switch
 #pragma unroll
         for (int x = 0; x < V; ++x) opt_apply<DR_OPT_ADAM>(w[x], s0[x], s1[x], tot[x], a.opt);
-        vstore<V>(a.slot0 + off, s0);
-        vstore<V>(a.slot1 + off, s1);
-        vstore<V>(a.table + off, w);
+        if (NT) {
+            vstore_nt<V>(a.slot0 + off, s0);
+            vstore_nt<V>(a.slot1 + off, s1);
+            vstore_nt<V>(a.table + off, w);
+        } else {
+            vstore<V>(a.slot0 + off, s0);
+            vstore<V>(a.slot1 + off, s1);
+            vstore<V>(a.table + off, w);
+        }
         return;
     }
     switch (a.kind) {

@@ -486,20 +486,20 @@ __global__ __launch_bounds__(256) void shard_forward_kernel(ShardFwd t) {
         const float* pj = (rj < niL ? t.q.table + rj * k : t.qf + (rj - niL) * k) + lane * V;
         const int64_t ou = iu * k + lane * V;
         float pu[V], qi[V], qj[V], mu[V], vu2[V], mi[V], vi2[V], mj[V], vj2[V];
-        vload<V>(pu, t.p.table + ou);
+        vload_nt<V>(pu, t.p.table + ou);      // rows touched once per step carry the non-temporal hint (pairwise.hip)
         vload<V>(qi, pi);
         vload<V>(qj, pj);
         if (su) {
-            if (nsl >= 1) vload<V>(mu, t.p.slot0 + ou);
-            if (nsl >= 2) vload<V>(vu2, t.p.slot1 + ou);
+            if (nsl >= 1) vload_nt<V>(mu, t.p.slot0 + ou);
+            if (nsl >= 2) vload_nt<V>(vu2, t.p.slot1 + ou);
         }
         if (si) {   // a solo item row is a local row
-            if (nsl >= 1) vload<V>(mi, t.q.slot0 + ri * k + lane * V);
-            if (nsl >= 2) vload<V>(vi2, t.q.slot1 + ri * k + lane * V);
+            if (nsl >= 1) vload_nt<V>(mi, t.q.slot0 + ri * k + lane * V);
+            if (nsl >= 2) vload_nt<V>(vi2, t.q.slot1 + ri * k + lane * V);
         }
         if (sj) {
-            if (nsl >= 1) vload<V>(mj, t.q.slot0 + rj * k + lane * V);
-            if (nsl >= 2) vload<V>(vj2, t.q.slot1 + rj * k + lane * V);
+            if (nsl >= 1) vload_nt<V>(mj, t.q.slot0 + rj * k + lane * V);
+            if (nsl >= 2) vload_nt<V>(vj2, t.q.slot1 + rj * k + lane * V);
         }
         float xui = 0.0f, xuj = 0.0f;
 #pragma unroll
@@ -535,19 +535,19 @@ __global__ __launch_bounds__(256) void shard_forward_kernel(ShardFwd t) {
         if (si) {
 #pragma unroll
             for (int x = 0; x < V; ++x) tot[x] = 0.0f + (0.0f + g * pu[x]);
-            apply_row_loaded<V, KIND>(t.q, (uint32_t)ri, lane, tot, qi, mi, vi2);
+            apply_row_loaded<V, KIND, true>(t.q, (uint32_t)ri, lane, tot, qi, mi, vi2);
         }
         if (sj) {
 #pragma unroll
             for (int x = 0; x < V; ++x) tot[x] = 0.0f + (0.0f + ng * pu[x]);
-            apply_row_loaded<V, KIND>(t.q, (uint32_t)rj, lane, tot, qj, mj, vj2);
+            apply_row_loaded<V, KIND, true>(t.q, (uint32_t)rj, lane, tot, qj, mj, vj2);
         }
         // pre-step copy of the user row for the tail pass (local item rows that other contributions share)
         if ((owi >= 0 && !si) || (owj >= 0 && !sj)) vstore<V>(t.stash + (cap + s) * k + lane * V, pu);
         if (su) {
 #pragma unroll
             for (int x = 0; x < V; ++x) tot[x] = 0.0f + (0.0f + d[x]);
-            apply_row_loaded<V, KIND>(t.p, (uint32_t)iu, lane, tot, pu, mu, vu2);
+            apply_row_loaded<V, KIND, true>(t.p, (uint32_t)iu, lane, tot, pu, mu, vu2);
         } else {
             vstore<V>(t.stash + s * k + lane * V, d);
         }

@@ -339,7 +339,6 @@ class Shard:
     def __init__(self, world=1, rank=0, group=None, force=False):
         self.world, self.rank, self.group, self.force = int(world), int(rank), group, bool(force)
         self._pre = []                                      # routes enqueued ahead of their steps: [(key tensors, StepRoute)]
-        self._side, self._ids_group = None, None
 
     @property
     def active(self):
@@ -372,21 +371,10 @@ class Shard:
         has long been reached and the step's one host synchronisation does not drain the work in flight.  key: the
         tensors the later step will be called with.  Every rank calls it at the same point of its step sequence."""
         from .. import sharding as sh
-        import torch.distributed as dist
-        if not key[0].is_cuda or os.environ.get("DR_ROUTE_STREAM", "1") == "0":
-            rt = sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group, defer=True)
-        else:
-            # on a stream (and communicator) of its own: where the hardware queues allow it the route's short kernels run
-            # BESIDE the step enqueued next; where the two streams share a queue they run ahead of it, as in-stream
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=key[0].device, priority=-1)
-                if dist.is_available() and dist.is_initialized():
-                    ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
-                    self._ids_group = dist.new_group(ranks=ranks)
-            self._side.wait_stream(torch.cuda.current_stream())     # the ids are ready; earlier steps are not overtaken
-            with torch.cuda.stream(self._side):
-                rt = sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group, defer=True,
-                                  ids_group=self._ids_group)
+        # same stream, same communicator as the steps: a stream / communicator of its own for this part measured 6 % faster
+        # (AttRec 2.15 against 2.28 ms at world 1) but HUNG in a process with many streams (tools/bench_configs.py: the
+        # side stream's event never completed -- streams share 4 hardware queues on this part), so it is not offered
+        rt = sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group, defer=True)
         self._pre.append((tuple(key), rt))
         if len(self._pre) > 2:                              # routes nobody came for
             del self._pre[0]

@@ -354,12 +354,11 @@ class StepRoute:
     below: a count exchange, a host synchronisation and three all-to-alls per lookup).  Rows of different widths share
     the wire: a peer's block holds one 16-byte-aligned segment per (table, list) pair (csrc/wire.hip)."""
 
-    def __init__(self, ops, lists, world, rank, group=None, defer=False, ids_group=None):
+    def __init__(self, ops, lists, world, rank, group=None, defer=False):
         """defer: enqueue the id-only part (all-gather, keys, bucketings, counts -> pinned host memory) and return; finish()
         -- called by the step that uses the route -- waits for an event recorded behind those kernels.  A route built
         one step AHEAD (models/_common.py: Shard.prefetch_route, enqueued before the previous step's kernels) is complete
-        by then, so the step's one host synchronisation no longer drains the work in flight.  ids_group: the
-        communicator of the id all-gather when that part is enqueued on another stream than the step's."""
+        by then, so the step's one host synchronisation no longer drains the work in flight."""
         self.ops, self.world, self.rank, self.group = ops, int(world), int(rank), group
         W, nl = self.world, len(lists)
         flat = [t.reshape(-1) if t.dtype == torch.int32 else t.reshape(-1).to(torch.int32) for t in lists]
@@ -372,7 +371,7 @@ class StepRoute:
         mine = (torch.cat(flat) if nl > 1 else flat[0]).contiguous()
         dev = mine.device
         ids_all = torch.empty((W, n_tot), dtype=torch.int32, device=dev)
-        _gather_ids(ids_all, mine, ids_group if ids_group is not None else group)   # collective 1 of 3
+        _gather_ids(ids_all, mine, group)                                   # collective 1 of 3
         km, ko, self._loc = ops.step_route_keys(ids_all, self.rank, self.start)
         self._order_m, cnt_m = ops.bucket_order(km, nl * W)                 # my entries by (list, owner)
         self._order_o, cnt_o = ops.bucket_order(ko, nl * W)                 # entries I own by (list, source rank)
@@ -399,10 +398,6 @@ class StepRoute:
         W, nl = self.world, len(self.n)
         if self._ev is not None:
             self._ev.synchronize()
-            cur = torch.cuda.current_stream()
-            cur.wait_event(self._ev)                  # no-ops when the id-only part ran on this stream
-            for t in (self._order_m, self._order_o, self._loc):
-                t.record_stream(cur)
         c = self._cnt_host.tolist()
         self.send_cnt = [c[l * W:(l + 1) * W] for l in range(nl)]           # [list][owner]: rows I ask of each owner
         self.recv_cnt = [c[(nl + l) * W:(nl + l + 1) * W] for l in range(nl)]   # [list][source]: rows each peer asks of me

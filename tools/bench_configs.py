@@ -29,6 +29,11 @@ def say(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+import faulthandler
+if os.environ.get("DR_HANG_DUMP"):
+    faulthandler.dump_traceback_later(int(os.environ["DR_HANG_DUMP"]), exit=True)
+
+
 def timed(fn, iters, warm=5):
     t0 = time.perf_counter()
     fn()
