@@ -1248,7 +1248,9 @@ __global__ __launch_bounds__(256) void dense_update_kernel(float* __restrict__ w
 
 // the same update on float4 elements (count % 4 == 0, 16-byte aligned tensors): four times fewer, wider memory
 // instructions on what is a pure streaming pass (Caser's [U, d L] table: 25.6 GB x 6 streams per step)
-template <int KIND>
+// NT: tables larger than the caches (>= DR_DENSE_NT_BYTES per stream) are streamed with the non-temporal hint, so that a
+// pass over a 0.5 - 25 GB table does not evict the small tables and activations the step's other kernels re-read
+template <int KIND, bool NT = false>
 __global__ __launch_bounds__(256) void dense_update4_kernel(float4* __restrict__ w, float4* __restrict__ s0p,
                                                             float4* __restrict__ s1p, const float4* __restrict__ grad,
                                                             int64_t count4, OptP o, const uint8_t* __restrict__ skip,
@@ -1258,22 +1260,33 @@ __global__ __launch_bounds__(256) void dense_update4_kernel(float4* __restrict__
         // k % 4 == 0: a float4 never straddles two rows.  32-bit division where the index allows it (a 64-bit one is
         // ~100 instructions on this pass of 4 loads and 3 stores)
         if (skip && skip[count4 <= 0xffffffffll ? (int64_t)((uint32_t)i / (uint32_t)k4) : i / k4]) continue;
-        const float4 w4 = w[i];
-        float4 g4 = grad ? grad[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b4 = a4;
-        if constexpr (KIND != DR_OPT_SGD) a4 = s0p[i];
-        if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) b4 = s1p[i];
-        float wv[4] = {w4.x, w4.y, w4.z, w4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
-        float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        float wv[4], gv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, av[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (NT) {
+            vload_nt<4>(wv, reinterpret_cast<const float*>(w + i));
+            if (grad) vload_nt<4>(gv, reinterpret_cast<const float*>(grad + i));
+            if constexpr (KIND != DR_OPT_SGD) vload_nt<4>(av, reinterpret_cast<const float*>(s0p + i));
+            if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) vload_nt<4>(bv, reinterpret_cast<const float*>(s1p + i));
+        } else {
+            vload<4>(wv, reinterpret_cast<const float*>(w + i));
+            if (grad) vload<4>(gv, reinterpret_cast<const float*>(grad + i));
+            if constexpr (KIND != DR_OPT_SGD) vload<4>(av, reinterpret_cast<const float*>(s0p + i));
+            if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) vload<4>(bv, reinterpret_cast<const float*>(s1p + i));
+        }
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             float g = gv[x];
             if (o.reg_mode != DR_REG_NONE) g = g + o.reg * wv[x];
             opt_apply<KIND>(wv[x], av[x], bv[x], g, o);
         }
-        w[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
-        if constexpr (KIND != DR_OPT_SGD) s0p[i] = make_float4(av[0], av[1], av[2], av[3]);
-        if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) s1p[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+        if (NT) {
+            vstore_nt<4>(reinterpret_cast<float*>(w + i), wv);
+            if constexpr (KIND != DR_OPT_SGD) vstore_nt<4>(reinterpret_cast<float*>(s0p + i), av);
+            if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) vstore_nt<4>(reinterpret_cast<float*>(s1p + i), bv);
+        } else {
+            vstore<4>(reinterpret_cast<float*>(w + i), wv);
+            if constexpr (KIND != DR_OPT_SGD) vstore<4>(reinterpret_cast<float*>(s0p + i), av);
+            if constexpr (KIND == DR_OPT_ADAM || KIND == DR_OPT_RMSPROP) vstore<4>(reinterpret_cast<float*>(s1p + i), bv);
+        }
     }
 }
 
@@ -1702,6 +1715,9 @@ extern "C" int32_t dr_sparse_row_update_f32(float* table, float* slot0, float* s
                       (hipStream_t)stream, false, SegSel{0, 0, 0}, 0, nullptr, false);
 }
 
+#ifndef DR_DENSE_NT_BYTES
+#define DR_DENSE_NT_BYTES (128ll << 20)
+#endif
 static int32_t dense_update_launch(const char* who, float* w, float* slot0, float* slot1, const float* grad,
                                    int64_t count, const dr_opt_params* opt, const uint8_t* skip, int k, void* stream) {
     DR_REQUIRE(count >= 0, "%s: negative count", who);
@@ -1716,9 +1732,14 @@ static int32_t dense_update_launch(const char* who, float* w, float* slot0, floa
     if (v4) {
         const int64_t c4 = count / 4;
         const int grid = grid_for(c4, 256, 2);
+        const bool nt = DR_DENSE_NT_BYTES > 0 && count * 4 >= (int64_t)DR_DENSE_NT_BYTES;
 #define DR_DU4(KIND_)                                                                                              \
-    DR_LAUNCH((dense_update4_kernel<KIND_>), dim3(grid), dim3(256), 0, st, (float4*)w, (float4*)slot0, (float4*)slot1, \
-              (const float4*)grad, c4, o, skip, k / 4)
+    if (nt)                                                                                                        \
+        DR_LAUNCH((dense_update4_kernel<KIND_, true>), dim3(grid), dim3(256), 0, st, (float4*)w, (float4*)slot0,   \
+                  (float4*)slot1, (const float4*)grad, c4, o, skip, k / 4);                                        \
+    else                                                                                                           \
+        DR_LAUNCH((dense_update4_kernel<KIND_>), dim3(grid), dim3(256), 0, st, (float4*)w, (float4*)slot0,         \
+                  (float4*)slot1, (const float4*)grad, c4, o, skip, k / 4)
         switch (opt->kind) {
             case DR_OPT_SGD: DR_DU4(DR_OPT_SGD); break;
             case DR_OPT_ADAM: DR_DU4(DR_OPT_ADAM); break;
