@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void bpr_forward_update_kernel(FusedTables t, 
 // (loads and stores), 2: + the stores of solo item rows, 3: + the slot loads of solo item rows.  Those rows have no
 // reuse to keep in L2 / Infinity Cache, and without the hint they evict the item rows that do (Zipf head).  Measured on the
 // C4 step (bench.py, median of 25 windows): 0.1555 ms -> 0.1488 (1) -> 0.1482 (2) -> 0.1465 (3); the same hint in the tail
-// kernel: no further change.
+// kernel: no further change; on the row LOADS of solo item rows as well (a branch per row): 0.1484, slightly slower.
 #ifndef DR_FWD_NT
 #define DR_FWD_NT 3
 #endif
