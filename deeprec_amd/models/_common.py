@@ -373,7 +373,8 @@ class Shard:
         from .. import sharding as sh
         # same stream, same communicator as the steps: a stream / communicator of its own for this part measured 6 % faster
         # (AttRec 2.15 against 2.28 ms at world 1) but HUNG in a process with many streams (tools/bench_configs.py: the
-        # side stream's event never completed -- streams share 4 hardware queues on this part), so it is not offered
+        # side stream's event never completed; that stream had priority -1, and a high-priority main stream in bench.py hung the
+        # same way later: no stream here has a priority), so it is not offered
         rt = sh.StepRoute(K, lists() if callable(lists) else lists, self.world, self.rank, self.group, defer=True)
         self._pre.append((tuple(key), rt))
         if len(self._pre) > 2:                              # routes nobody came for
