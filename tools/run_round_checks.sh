@@ -21,7 +21,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sharded -o s -- python $R/bench.py --sharded --steps 20 --warmup 5 --windows 5 --no-cpu-baseline --no-extras > $R/gpurun_out/prof_sharded.log 2>&1
 cd $R
 timeout -k 10 600 python tools/bench_configs.py gpurun_out/r03_configs.json > /dev/null 2> gpurun_out/configs_r3.err || { tail -5 gpurun_out/configs_r3.err; exit 1; }
-for m in c4 c4r c5 c5r c5c c5x; do timeout -k 10 120 python tools/eval_probe.py $m 3 2>/dev/null; done > gpurun_out/eval_probe_r3.txt
+for m in c4 c4r c4m c5 c5r c5c c5x; do timeout -k 10 120 python tools/eval_probe.py $m 3 2>/dev/null; done > gpurun_out/eval_probe_r3.txt
 cat gpurun_out/eval_probe_r3.txt
 python - <<'PY'
 import json
