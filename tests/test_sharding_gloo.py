@@ -294,7 +294,13 @@ def _route_worker(rank, world, port, seed, out):
         T1, T2, bv, lists, grads = _route_case(seed, world)
         shd = Shard(world, rank)
         tabs = [Table(torch.from_numpy(np.ascontiguousarray(a[rank::world])), shd) for a in (T1, T2, bv)]
-        rt = sh.StepRoute(ops, [torch.from_numpy(x) for x in lists[rank]], world, rank)
+        # worlds 2 and 3 build the route in its deferred form (the id-only part first, finish() when the step needs it:
+        # what Shard.prefetch_route does one step ahead); world 1 in one go
+        rt = sh.StepRoute(ops, [torch.from_numpy(x) for x in lists[rank]], world, rank, defer=world > 1)
+        if world > 1:
+            assert not hasattr(rt, "send_cnt")
+            rt.finish()
+            rt.finish()         # idempotent
         fr = rt.fetch([(tabs[0], 0), (tabs[1], 1), (tabs[2], 1)])
         # gradients arrive in the order a backward pass would record them: pair 2 first, then 0, then 1
         for f in (2, 0, 1):
